@@ -1,0 +1,95 @@
+"""ctypes binding of libgfy.so (the C ABI in include/gfy.h).
+
+There is no fallback: if the HIP library is missing or a call fails, the
+caller gets an exception.  The product never routes around the kernels.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import (POINTER, c_char_p, c_int, c_int32, c_int64, c_size_t,
+                    c_uint32, c_void_p)
+from pathlib import Path
+
+LIBRARY_PATH = Path(__file__).resolve().parent / "csrc" / "libgfy.so"
+
+GFY_OK = 0
+GFY_ERR_INVALID, GFY_ERR_UNSUPPORTED, GFY_ERR_HIP, GFY_ERR_WORKSPACE = 1, 2, 3, 4
+GFY_F16, GFY_F32, GFY_F64 = 0, 1, 2
+GFY_L2, GFY_COSINE = 0, 1
+ABI_VERSION = 1
+
+#: every symbol include/gfy.h declares: (restype, argtypes)
+SIGNATURES: dict[str, tuple] = {
+    "gfy_last_error": (c_char_p, []),
+    "gfy_abi_version": (c_int, []),
+    "gfy_weight_pack_bytes": (c_size_t, [c_uint32] * 5),
+    "gfy_encoder_create": (c_int, [c_void_p, c_size_t, c_int, c_int,
+                                   POINTER(c_void_p)]),
+    "gfy_encoder_destroy": (None, [c_void_p]),
+    "gfy_csr_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "gfy_build_csr": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p,
+                              c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "gfy_encode_workspace_bytes": (c_size_t, [c_void_p, c_int64, c_int64]),
+    "gfy_encode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                           c_int64, c_int64, c_void_p, c_void_p, c_int, c_int,
+                           c_void_p, c_size_t, c_void_p]),
+    "gfy_encode_hidden": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_int64, c_int64, c_int, c_void_p,
+                                  c_void_p, c_size_t, c_void_p]),
+    "gfy_pairwise_dense": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int,
+                                   c_void_p, c_void_p]),
+    "gfy_pairwise_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "gfy_pairwise_nearest": (c_int, [c_void_p, c_int64, c_void_p, c_int64,
+                                     c_int, c_int64, c_void_p, c_void_p,
+                                     c_void_p, c_size_t, c_void_p]),
+}
+
+
+class NativeLibraryError(RuntimeError):
+    """libgfy.so is missing, stale or reported a failure."""
+
+
+_library: ctypes.CDLL | None = None
+
+
+def library() -> ctypes.CDLL:
+    """Load libgfy.so once; raise loudly when it is not built."""
+    global _library
+    if _library is not None:
+        return _library
+    if not LIBRARY_PATH.is_file():
+        raise NativeLibraryError(
+            f"HIP extension not built: {LIBRARY_PATH} is missing. Run "
+            "`python -m ginfinity_amd.build` (needs hipcc, gfx950). There is "
+            "no CPU fallback in this package.")
+    try:
+        lib = ctypes.CDLL(str(LIBRARY_PATH), mode=ctypes.RTLD_GLOBAL)
+    except OSError as error:
+        raise NativeLibraryError(
+            f"cannot load {LIBRARY_PATH}: {error}") from error
+    for name, (restype, argtypes) in SIGNATURES.items():
+        try:
+            function = getattr(lib, name)
+        except AttributeError as error:
+            raise NativeLibraryError(
+                f"{LIBRARY_PATH} does not export {name}; rebuild it") from error
+        function.restype = restype
+        function.argtypes = argtypes
+    if lib.gfy_abi_version() != ABI_VERSION:
+        raise NativeLibraryError(
+            f"{LIBRARY_PATH} has ABI {lib.gfy_abi_version()}, "
+            f"expected {ABI_VERSION}; rebuild it")
+    _library = lib
+    return lib
+
+
+def check(status: int, where: str) -> None:
+    """Turn a gfy status into the reference's exception conventions:
+    invalid arguments → ValueError, everything else → NativeLibraryError."""
+    if status == GFY_OK:
+        return
+    message = library().gfy_last_error().decode("utf-8", "replace")
+    text = f"{where}: {message or 'status ' + str(status)}"
+    if status == GFY_ERR_INVALID:
+        raise ValueError(text)
+    raise NativeLibraryError(text)

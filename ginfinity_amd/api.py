@@ -1,0 +1,231 @@
+"""Public embedding API — the drop-in for ``ginfinity.Ginfinity``.
+
+Same method names, keyword arguments, return types and error behaviour as the
+reference (src/ginfinity/api.py:53-260); the compute under
+``_run_graph_shard`` is the HIP path of libgfy instead of a ``torch.nn``
+module.  Differences a user can observe, all deliberate:
+
+* the device is an AMD GPU: ``device`` must be ``"cuda"``/``"cuda:i"`` (the HIP
+  device under PyTorch-ROCm).  ``device="cpu"`` raises — this package has no
+  CPU compute path (the CPU restatement lives in ``oracle/`` for tests only);
+* the kernels are deterministic (no atomics in the float path), so
+  ``allow_nondeterministic_cuda`` is accepted for compatibility but not
+  required;
+* the per-record arrays returned by one call are views into one host block
+  (C-contiguous, independent rows) instead of separate allocations.
+"""
+from __future__ import annotations
+
+import json
+from pathlib import Path
+from typing import Sequence
+
+import numpy as np
+import torch
+
+from .engine import DeviceEncoder, device_output_dtype
+from .graph import Graph, GraphBuilder, GraphShard
+from .records import RNA
+from .spec import DATA_DIRECTORY, GraphCompatibilityError, GraphSpec
+from .weights import LoadedCheckpoint, ModelIntegrityError, load_checkpoint
+
+
+def _embedding_dtype(value: np.dtype | str) -> np.dtype:
+    try:
+        dtype = np.dtype(value)
+    except TypeError as error:
+        raise ValueError(f"unsupported embedding dtype {value!r}") from error
+    if dtype.kind != "f":
+        raise ValueError(f"embedding dtype must be floating-point, got {dtype}")
+    return dtype
+
+
+def default_alignment_parameters() -> dict[str, float]:
+    """Model-versioned scoring parameters for the separate aligner package
+    (passthrough; reference api.py:47-50)."""
+    try:
+        data = json.loads((DATA_DIRECTORY / "alignment.json").read_text())
+    except (OSError, json.JSONDecodeError) as error:
+        raise ModelIntegrityError(
+            f"cannot read model metadata: {error}") from error
+    return dict(data["scoring_parameters"])
+
+
+def microbatch_bounds(lengths: Sequence[int], edge_counts: Sequence[int],
+                      max_batch_nodes: int, max_batch_edges: int
+                      ) -> list[tuple[int, int]]:
+    """Greedy contiguous packing of records into micro-batches, as
+    ``encode_graphs`` does it (api.py:211-230): a record joins the current
+    batch unless that would exceed either limit; a batch always holds at least
+    one record."""
+    bounds: list[tuple[int, int]] = []
+    start, total = 0, len(lengths)
+    while start < total:
+        nodes, edges, stop = lengths[start], edge_counts[start], start + 1
+        while (stop < total and nodes + lengths[stop] <= max_batch_nodes
+               and edges + edge_counts[stop] <= max_batch_edges):
+            nodes += lengths[stop]
+            edges += edge_counts[stop]
+            stop += 1
+        bounds.append((start, stop))
+        start = stop
+    return bounds
+
+
+class Ginfinity:
+    """Loaded GINFINITY encoder, resident on one MI355X, ready for repeated
+    inference."""
+
+    def __init__(self, engine: DeviceEncoder, checkpoint: LoadedCheckpoint,
+                 device: str, *, full_precision: bool) -> None:
+        self._engine = engine
+        self._metadata = checkpoint.metadata
+        self._config = checkpoint.config
+        self._graph_spec = checkpoint.graph_spec
+        self.device = device
+        self.full_precision = full_precision
+
+    @classmethod
+    def load(cls, device: str = "cuda", *,
+             allow_nondeterministic_cuda: bool = False,
+             model_dir: str | Path | None = None,
+             full_precision: bool = False) -> "Ginfinity":
+        del allow_nondeterministic_cuda      # deterministic kernels: no ack needed
+        if device == "cpu":
+            raise ValueError(
+                "this build runs the encoder on an AMD GPU only: use "
+                "device='cuda' (or 'cuda:<index>'); there is no CPU compute path")
+        if not isinstance(device, str) or not device.startswith("cuda"):
+            raise ValueError("device must be 'cpu' or a CUDA device")
+        if not torch.cuda.is_available():
+            raise ValueError("CUDA was requested but is unavailable")
+        checkpoint = load_checkpoint(model_dir)
+        engine = DeviceEncoder(checkpoint.weight_pack,
+                               full_precision=full_precision,
+                               device=torch.device(device))
+        return cls(engine, checkpoint, device, full_precision=full_precision)
+
+    # -- metadata -----------------------------------------------------------------
+    @property
+    def embedding_dimension(self) -> int:
+        return self._config.out_dim
+
+    @property
+    def graph_spec(self) -> GraphSpec:
+        """The graph contract accepted by this encoder."""
+        return self._graph_spec
+
+    def info(self) -> dict:
+        return json.loads(json.dumps(self._metadata))
+
+    # -- records in → embeddings out ---------------------------------------------------
+    def encode(self, record: RNA, *, keep_paired_neighbours: bool = False,
+               context_hops: int = 1,
+               embedding_dtype: np.dtype | str = np.float16) -> np.ndarray:
+        return self.encode_many(
+            [record], keep_paired_neighbours=keep_paired_neighbours,
+            context_hops=context_hops, embedding_dtype=embedding_dtype)[0]
+
+    def encode_many(self, records: Sequence[RNA], *,
+                    max_batch_nodes: int = 60_000,
+                    max_batch_edges: int = 300_000,
+                    keep_paired_neighbours: bool = False,
+                    context_hops: int = 1,
+                    embedding_dtype: np.dtype | str = np.float16
+                    ) -> list[np.ndarray]:
+        """Build graphs and encode them.  For sliced records the context
+        nucleotides take part in message passing and are dropped afterwards:
+        each returned array holds the core nucleotides only, 5'→3'."""
+        records = list(records)
+        if not records:
+            return []
+        shard = GraphBuilder(
+            self._graph_spec, keep_paired_neighbours=keep_paired_neighbours,
+            context_hops=context_hops).build_shard(records)
+        return self.encode_graphs(
+            shard, max_batch_nodes=max_batch_nodes,
+            max_batch_edges=max_batch_edges, embedding_dtype=embedding_dtype)
+
+    def encode_graph(self, graph: Graph, *,
+                     embedding_dtype: np.dtype | str = np.float16) -> np.ndarray:
+        return self.encode_graphs([graph], embedding_dtype=embedding_dtype)[0]
+
+    def _checked_shard(self, graphs: Sequence[Graph] | GraphShard,
+                       max_batch_nodes: int, max_batch_edges: int
+                       ) -> GraphShard | None:
+        if isinstance(graphs, GraphShard):
+            shard = graphs
+        else:
+            graphs = list(graphs)
+            if not graphs:
+                return None
+            shard = GraphShard.from_graphs(graphs)
+        if shard.spec.sha256 != self._graph_spec.sha256:
+            raise GraphCompatibilityError(
+                "graphs were built with a specification incompatible with "
+                "this encoder")
+        if max_batch_nodes <= 0 or max_batch_edges <= 0:
+            raise ValueError("batch node and edge limits must be positive")
+        if max(shard.lengths) > max_batch_nodes:
+            raise ValueError("max_batch_nodes is smaller than the longest graph")
+        if max(shard.edge_counts) > max_batch_edges:
+            raise ValueError("max_batch_edges is smaller than the largest graph")
+        return shard
+
+    def encode_graphs(self, graphs: Sequence[Graph] | GraphShard, *,
+                      max_batch_nodes: int = 60_000,
+                      max_batch_edges: int = 300_000,
+                      embedding_dtype: np.dtype | str = np.float16
+                      ) -> list[np.ndarray]:
+        """Encode prebuilt graphs, micro-batching a persistent shard."""
+        shard = self._checked_shard(graphs, max_batch_nodes, max_batch_edges)
+        if shard is None:
+            return []
+        embedding_dtype = _embedding_dtype(embedding_dtype)
+        outputs: list[np.ndarray] = []
+        for start, stop in microbatch_bounds(
+                shard.lengths, shard.edge_counts,
+                max_batch_nodes, max_batch_edges):
+            piece = (shard if (start, stop) == (0, shard.record_count)
+                     else shard.slice(start, stop))
+            outputs.extend(self._run_graph_shard(piece, embedding_dtype))
+        return outputs
+
+    # -- the seam (reference: api.py:232-260) -----------------------------------------
+    def _encode_shard_device(self, shard: GraphShard, out_dtype: torch.dtype
+                             ) -> torch.Tensor:
+        """One micro-batch → [core_nodes,128] tensor left on the device."""
+        return self._engine.encode_arrays(
+            shard.node_features, shard.edge_index, shard.edge_types,
+            shard.node_roles, out_dtype=out_dtype, normalise=True)
+
+    def _run_graph_shard(self, shard: GraphShard, embedding_dtype: np.dtype
+                         ) -> list[np.ndarray]:
+        torch_dtype, _code, exact = device_output_dtype(embedding_dtype)
+        block = self._encode_shard_device(shard, torch_dtype).cpu().numpy()
+        if not exact:
+            block = block.astype(embedding_dtype)
+        cuts = np.cumsum(shard.core_counts)[:-1]
+        return np.split(block, cuts, axis=0)
+
+    def encode_graphs_device(self, shard: GraphShard, *,
+                             max_batch_nodes: int = 60_000,
+                             max_batch_edges: int = 300_000
+                             ) -> tuple[torch.Tensor, tuple[int, ...]]:
+        """MI355X-side extension: fp16 embeddings of the whole shard as ONE
+        device tensor ([total core nodes, 128]) plus the per-record row counts —
+        the input format of ``ginfinity_amd.distance``; nothing returns to
+        the host."""
+        shard = self._checked_shard(shard, max_batch_nodes, max_batch_edges)
+        pieces = [
+            self._encode_shard_device(
+                shard if (a, b) == (0, shard.record_count) else shard.slice(a, b),
+                torch.float16)
+            for a, b in microbatch_bounds(shard.lengths, shard.edge_counts,
+                                          max_batch_nodes, max_batch_edges)]
+        block = pieces[0] if len(pieces) == 1 else torch.cat(pieces, dim=0)
+        return block, shard.core_counts
+
+
+__all__ = ["Ginfinity", "ModelIntegrityError", "default_alignment_parameters",
+           "microbatch_bounds"]

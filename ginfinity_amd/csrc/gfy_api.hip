@@ -1,0 +1,430 @@
+// C ABI of libgfy (include/gfy.h): argument checking, weight-pack parsing and
+// the host-side derivation of everything the fp16 kernels consume.
+//
+// Reference behaviour reproduced here (host side, once per encoder):
+//   model.half()                       src/ginfinity/api.py:111-112
+//   edge_lin on a one-hot row          src/ginfinity/_model.py:43   -> 10-row table
+//   (1 + eps) formed in fp16           src/ginfinity/_model.py:46
+//   BatchNorm1d eval affine in fp32    src/ginfinity/_model.py:35
+// The rounding points follow SURVEY.md §8-A / oracle/gine_numpy.py.
+// Compiled with -ffp-contract=off: alpha/shift must round after every step.
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "gfy_common.h"
+
+namespace gfy {
+
+static thread_local std::string g_error;
+
+void set_error(const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_error = buf;
+}
+void clear_error() { g_error.clear(); }
+
+void pack_b_fragments(const f16* w, int n_out, int k_in, f16* frag) {
+  const int tiles = n_out / 32, ksteps = k_in / 16;
+  for (int tile = 0; tile < tiles; ++tile)
+    for (int ks = 0; ks < ksteps; ++ks)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j)
+          frag[(((size_t)tile * ksteps + ks) * 64 + lane) * 8 + j] =
+              w[(size_t)(32 * tile + (lane & 31)) * k_in + 16 * ks +
+                8 * (lane >> 5) + j];
+}
+
+namespace {
+
+constexpr uint32_t kMagic = 0x31594647u;  // 'GFY1'
+
+struct PackHeader {
+  uint32_t magic, version, in_dim, hidden, layers, edge_dim, out_dim, flags;
+};
+
+size_t pack_floats(uint32_t in_dim, uint32_t h, uint32_t layers,
+                   uint32_t edge_dim, uint32_t out_dim) {
+  const size_t per_layer = 1 + (size_t)h * edge_dim + h + (size_t)2 * h * h +
+                           2 * h + 4 * (size_t)(2 * h) + (size_t)h * 2 * h + h +
+                           2 * h;
+  return (size_t)h * in_dim + h + layers * per_layer + (size_t)h * h + h +
+         (size_t)out_dim * h + out_dim;
+}
+
+// bump allocator over a host staging image of the device blob
+struct Blob {
+  std::vector<char> host;
+  size_t reserve(size_t bytes) {
+    const size_t at = align_up(host.size(), 256);
+    host.resize(at + bytes, 0);
+    return at;
+  }
+  template <typename T>
+  T* at(size_t off) { return reinterpret_cast<T*>(host.data() + off); }
+};
+
+inline f16 rh(float v) { return (f16)v; }  // RNE, as torch's .half()
+
+struct Reader {
+  const float* p;
+  const float* take(size_t n) {
+    const float* r = p;
+    p += n;
+    return r;
+  }
+};
+
+}  // namespace
+}  // namespace gfy
+
+using namespace gfy;
+
+extern "C" {
+
+const char* gfy_last_error(void) { return g_error.c_str(); }
+int gfy_abi_version(void) { return GFY_ABI_VERSION; }
+
+size_t gfy_weight_pack_bytes(uint32_t in_dim, uint32_t hidden, uint32_t layers,
+                             uint32_t edge_dim, uint32_t out_dim) {
+  return sizeof(PackHeader) +
+         4 * pack_floats(in_dim, hidden, layers, edge_dim, out_dim);
+}
+
+int gfy_encoder_create(const void* weight_pack_host, size_t bytes,
+                       int model_dtype, int device, gfy_encoder** out) {
+  clear_error();
+  GFY_REQUIRE(out != nullptr, GFY_ERR_INVALID, "gfy_encoder_create: out is NULL");
+  *out = nullptr;
+  GFY_REQUIRE(weight_pack_host && bytes >= sizeof(PackHeader), GFY_ERR_INVALID,
+              "gfy_encoder_create: weight pack missing or truncated");
+  PackHeader hd;
+  std::memcpy(&hd, weight_pack_host, sizeof hd);
+  GFY_REQUIRE(hd.magic == kMagic && hd.version == 1, GFY_ERR_INVALID,
+              "gfy_encoder_create: bad weight-pack magic/version");
+  GFY_REQUIRE(hd.hidden == (uint32_t)kHidden && hd.in_dim == (uint32_t)kInDim &&
+                  hd.out_dim == (uint32_t)kOutDim,
+              GFY_ERR_UNSUPPORTED,
+              "gfy_encoder_create: kernels are built for in_dim=7 hidden=128 "
+              "out_dim=128 (got %u/%u/%u)",
+              hd.in_dim, hd.hidden, hd.out_dim);
+  GFY_REQUIRE(hd.layers >= 1 && hd.layers <= (uint32_t)kMaxLayers,
+              GFY_ERR_UNSUPPORTED, "gfy_encoder_create: layers=%u outside 1..%d",
+              hd.layers, kMaxLayers);
+  GFY_REQUIRE(hd.edge_dim >= 1 && hd.edge_dim <= (uint32_t)kMaxEdgeTypes,
+              GFY_ERR_UNSUPPORTED, "gfy_encoder_create: edge_dim=%u outside 1..%d",
+              hd.edge_dim, kMaxEdgeTypes);
+  GFY_REQUIRE(bytes == gfy_weight_pack_bytes(hd.in_dim, hd.hidden, hd.layers,
+                                             hd.edge_dim, hd.out_dim),
+              GFY_ERR_INVALID, "gfy_encoder_create: weight pack is %zu bytes, expected %zu",
+              bytes,
+              gfy_weight_pack_bytes(hd.in_dim, hd.hidden, hd.layers, hd.edge_dim,
+                                    hd.out_dim));
+  GFY_REQUIRE(model_dtype == GFY_F16 || model_dtype == GFY_F32, GFY_ERR_INVALID,
+              "gfy_encoder_create: model_dtype must be GFY_F16 or GFY_F32");
+  GFY_CHECK_HIP(hipSetDevice(device));
+
+  const int H = kHidden, M = kMlp, L = (int)hd.layers, ED = (int)hd.edge_dim;
+  Reader rd{reinterpret_cast<const float*>((const char*)weight_pack_host +
+                                           sizeof(PackHeader))};
+  gfy_encoder* enc = new gfy_encoder();
+  enc->device = device;
+  enc->model_dtype = model_dtype;
+  enc->layers = L;
+  enc->edge_dim = ED;
+  enc->residual = (int)(hd.flags & 1u);
+
+  Blob blob;
+  // offsets first (pointers are fixed up after the single upload)
+  struct LayerOff {
+    size_t table, w0, b0, alpha, shift, w1, b1, lg, lb;               // f16 mode
+    size_t ew, eb, fw0, fb0, g, b, mean, var, fw1, fb1, flg, flb;     // f32 mode
+    float scale, eps;
+  };
+  size_t o_win = 0, o_bin = 0, o_wa = 0, o_ba = 0, o_wb = 0, o_bb = 0;
+  std::vector<LayerOff> lo(L);
+
+  const float* w_in = rd.take((size_t)H * kInDim);
+  const float* b_in = rd.take(H);
+  if (model_dtype == GFY_F16) {
+    o_win = blob.reserve((size_t)H * 8 * sizeof(f16));
+    o_bin = blob.reserve(H * sizeof(f16));
+    for (int c = 0; c < H; ++c) {
+      for (int k = 0; k < kInDim; ++k)
+        blob.at<f16>(o_win)[c * 8 + k] = rh(w_in[c * kInDim + k]);
+      blob.at<f16>(o_bin)[c] = rh(b_in[c]);
+    }
+  } else {
+    o_win = blob.reserve((size_t)H * kInDim * 4);
+    o_bin = blob.reserve(H * 4);
+    std::memcpy(blob.at<float>(o_win), w_in, (size_t)H * kInDim * 4);
+    std::memcpy(blob.at<float>(o_bin), b_in, H * 4);
+  }
+
+  std::vector<f16> tmp;
+  for (int l = 0; l < L; ++l) {
+    const float* eps = rd.take(1);
+    const float* ew = rd.take((size_t)H * ED);
+    const float* eb = rd.take(H);
+    const float* w0 = rd.take((size_t)M * H);
+    const float* b0 = rd.take(M);
+    const float* bg = rd.take(M);
+    const float* bb = rd.take(M);
+    const float* bm = rd.take(M);
+    const float* bv = rd.take(M);
+    const float* w1 = rd.take((size_t)H * M);
+    const float* b1 = rd.take(H);
+    const float* lg = rd.take(H);
+    const float* lb = rd.take(H);
+    LayerOff& o = lo[l];
+    if (model_dtype == GFY_F16) {
+      o.table = blob.reserve((size_t)kMaxEdgeTypes * H * sizeof(f16));
+      for (int t = 0; t < ED; ++t)
+        for (int c = 0; c < H; ++c)  // R(R(W[c][t]) + R(b[c]))  — one-hot Linear
+          blob.at<f16>(o.table)[t * H + c] =
+              rh((float)rh(ew[c * ED + t]) + (float)rh(eb[c]));
+      o.scale = (float)rh(1.0f + (float)rh(eps[0]));  // fp16 scalar (1 + eps)
+      tmp.resize((size_t)M * H);
+      for (size_t i = 0; i < tmp.size(); ++i) tmp[i] = rh(w0[i]);
+      o.w0 = blob.reserve(tmp.size() * sizeof(f16));
+      pack_b_fragments(tmp.data(), M, H, blob.at<f16>(o.w0));
+      for (size_t i = 0; i < tmp.size(); ++i) tmp[i] = rh(w1[i]);
+      o.w1 = blob.reserve(tmp.size() * sizeof(f16));
+      pack_b_fragments(tmp.data(), H, M, blob.at<f16>(o.w1));
+      o.b0 = blob.reserve(M * sizeof(f16));
+      o.alpha = blob.reserve(M * 4);
+      o.shift = blob.reserve(M * 4);
+      for (int c = 0; c < M; ++c) {
+        blob.at<f16>(o.b0)[c] = rh(b0[c]);
+        const float g = (float)rh(bg[c]), b = (float)rh(bb[c]);
+        const float mean = (float)rh(bm[c]), var = (float)rh(bv[c]);
+        const float invstd = 1.0f / std::sqrt(var + 1e-5f);
+        const float alpha = invstd * g;
+        const float prod = mean * alpha;  // separate rounding (no fma)
+        blob.at<float>(o.alpha)[c] = alpha;
+        blob.at<float>(o.shift)[c] = b - prod;
+      }
+      o.b1 = blob.reserve(H * sizeof(f16));
+      o.lg = blob.reserve(H * sizeof(f16));
+      o.lb = blob.reserve(H * sizeof(f16));
+      for (int c = 0; c < H; ++c) {
+        blob.at<f16>(o.b1)[c] = rh(b1[c]);
+        blob.at<f16>(o.lg)[c] = rh(lg[c]);
+        blob.at<f16>(o.lb)[c] = rh(lb[c]);
+      }
+    } else {
+      auto put = [&](const float* src, size_t n) {
+        const size_t off = blob.reserve(n * 4);
+        std::memcpy(blob.at<float>(off), src, n * 4);
+        return off;
+      };
+      o.eps = eps[0];
+      o.ew = put(ew, (size_t)H * ED);
+      o.eb = put(eb, H);
+      o.fw0 = put(w0, (size_t)M * H);
+      o.fb0 = put(b0, M);
+      o.g = put(bg, M);
+      o.b = put(bb, M);
+      o.mean = put(bm, M);
+      o.var = put(bv, M);
+      o.fw1 = put(w1, (size_t)H * M);
+      o.fb1 = put(b1, H);
+      o.flg = put(lg, H);
+      o.flb = put(lb, H);
+    }
+  }
+  const float* wa = rd.take((size_t)H * H);
+  const float* ba = rd.take(H);
+  const float* wb = rd.take((size_t)kOutDim * H);
+  const float* bbias = rd.take(kOutDim);
+  if (model_dtype == GFY_F16) {
+    tmp.resize((size_t)H * H);
+    for (size_t i = 0; i < tmp.size(); ++i) tmp[i] = rh(wa[i]);
+    o_wa = blob.reserve(tmp.size() * sizeof(f16));
+    pack_b_fragments(tmp.data(), H, H, blob.at<f16>(o_wa));
+    for (size_t i = 0; i < tmp.size(); ++i) tmp[i] = rh(wb[i]);
+    o_wb = blob.reserve(tmp.size() * sizeof(f16));
+    pack_b_fragments(tmp.data(), kOutDim, H, blob.at<f16>(o_wb));
+    o_ba = blob.reserve(H * sizeof(f16));
+    o_bb = blob.reserve(kOutDim * sizeof(f16));
+    for (int c = 0; c < H; ++c) {
+      blob.at<f16>(o_ba)[c] = rh(ba[c]);
+      blob.at<f16>(o_bb)[c] = rh(bbias[c]);
+    }
+  } else {
+    o_wa = blob.reserve((size_t)H * H * 4);
+    std::memcpy(blob.at<float>(o_wa), wa, (size_t)H * H * 4);
+    o_ba = blob.reserve(H * 4);
+    std::memcpy(blob.at<float>(o_ba), ba, H * 4);
+    o_wb = blob.reserve((size_t)kOutDim * H * 4);
+    std::memcpy(blob.at<float>(o_wb), wb, (size_t)kOutDim * H * 4);
+    o_bb = blob.reserve(kOutDim * 4);
+    std::memcpy(blob.at<float>(o_bb), bbias, kOutDim * 4);
+  }
+
+  void* dev = nullptr;
+  hipError_t err = hipMalloc(&dev, blob.host.size());
+  if (err == hipSuccess)
+    err = hipMemcpy(dev, blob.host.data(), blob.host.size(), hipMemcpyHostToDevice);
+  if (err != hipSuccess) {
+    if (dev) (void)hipFree(dev);
+    delete enc;
+    set_error("gfy_encoder_create: device upload failed: %s", hipGetErrorString(err));
+    return GFY_ERR_HIP;
+  }
+  enc->device_blob = dev;
+  enc->device_blob_bytes = blob.host.size();
+  char* base = (char*)dev;
+  auto H16 = [&](size_t off) { return (const f16*)(base + off); };
+  auto F32p = [&](size_t off) { return (const float*)(base + off); };
+  if (model_dtype == GFY_F16) {
+    enc->f16.w_in = H16(o_win);
+    enc->f16.b_in = H16(o_bin);
+    for (int l = 0; l < L; ++l) {
+      LayerF16& d = enc->f16.layer[l];
+      const LayerOff& o = lo[l];
+      d.edge_table = H16(o.table);
+      d.scale = o.scale;
+      d.w0_frag = H16(o.w0);
+      d.b0 = H16(o.b0);
+      d.bn_alpha = F32p(o.alpha);
+      d.bn_shift = F32p(o.shift);
+      d.w1_frag = H16(o.w1);
+      d.b1 = H16(o.b1);
+      d.ln_gamma = H16(o.lg);
+      d.ln_beta = H16(o.lb);
+    }
+    enc->f16.head = HeadF16{H16(o_wa), H16(o_ba), H16(o_wb), H16(o_bb)};
+  } else {
+    enc->f32.w_in = F32p(o_win);
+    enc->f32.b_in = F32p(o_bin);
+    for (int l = 0; l < L; ++l) {
+      LayerF32& d = enc->f32.layer[l];
+      const LayerOff& o = lo[l];
+      d.edge_w = F32p(o.ew);
+      d.edge_b = F32p(o.eb);
+      d.eps = o.eps;
+      d.w0 = F32p(o.fw0);
+      d.b0 = F32p(o.fb0);
+      d.bn_g = F32p(o.g);
+      d.bn_b = F32p(o.b);
+      d.bn_mean = F32p(o.mean);
+      d.bn_var = F32p(o.var);
+      d.w1 = F32p(o.fw1);
+      d.b1 = F32p(o.fb1);
+      d.ln_g = F32p(o.flg);
+      d.ln_b = F32p(o.flb);
+    }
+    enc->f32.ha_w = F32p(o_wa);
+    enc->f32.ha_b = F32p(o_ba);
+    enc->f32.hb_w = F32p(o_wb);
+    enc->f32.hb_b = F32p(o_bb);
+  }
+  *out = enc;
+  return GFY_OK;
+}
+
+void gfy_encoder_destroy(gfy_encoder* enc) {
+  if (!enc) return;
+  if (enc->device_blob) (void)hipFree(enc->device_blob);
+  delete enc;
+}
+
+size_t gfy_csr_workspace_bytes(int64_t n, int64_t e) {
+  return csr_workspace_bytes(n < 1 ? 1 : n, e < 0 ? 0 : e);
+}
+
+int gfy_build_csr(const int32_t* edge_index, const uint8_t* edge_types,
+                  int64_t n, int64_t e, int32_t* row_ptr, int32_t* col,
+                  uint8_t* typ, void* ws, size_t ws_bytes, void* stream) {
+  clear_error();
+  GFY_REQUIRE(row_ptr && ws, GFY_ERR_INVALID, "gfy_build_csr: NULL output/workspace");
+  GFY_REQUIRE(e == 0 || (edge_index && edge_types && col && typ), GFY_ERR_INVALID,
+              "gfy_build_csr: NULL edge array with E=%lld", (long long)e);
+  return launch_build_csr(edge_index, edge_types, n, e, row_ptr, col, typ, ws,
+                          ws_bytes, (hipStream_t)stream);
+}
+
+size_t gfy_encode_workspace_bytes(const gfy_encoder* enc, int64_t n, int64_t e) {
+  if (!enc) return 0;
+  n = n < 1 ? 1 : n;
+  return enc->model_dtype == GFY_F16 ? encode_f16_workspace_bytes(n, e)
+                                     : encode_f32_workspace_bytes(n, e);
+}
+
+static int encode_common(gfy_encoder* enc, const float* x, const int32_t* row_ptr,
+                         const int32_t* col, const uint8_t* typ, int64_t n,
+                         int64_t e, const int32_t* out_rows, void* out,
+                         int out_dtype, int normalise, int tap, void* ws,
+                         size_t ws_bytes, void* stream) {
+  clear_error();
+  GFY_REQUIRE(enc != nullptr, GFY_ERR_INVALID, "gfy_encode: encoder is NULL");
+  GFY_REQUIRE(n > 0 && n < INT32_MAX && e >= 0 && e < INT32_MAX, GFY_ERR_INVALID,
+              "gfy_encode: n=%lld e=%lld out of range", (long long)n, (long long)e);
+  GFY_REQUIRE(x && row_ptr && out && ws, GFY_ERR_INVALID, "gfy_encode: NULL argument");
+  GFY_REQUIRE(e == 0 || (col && typ), GFY_ERR_INVALID, "gfy_encode: NULL CSR arrays");
+  GFY_REQUIRE(out_dtype == GFY_F16 || out_dtype == GFY_F32 || out_dtype == GFY_F64,
+              GFY_ERR_INVALID, "gfy_encode: unsupported out_dtype %d", out_dtype);
+  GFY_REQUIRE(tap < 0 || tap <= enc->layers, GFY_ERR_INVALID,
+              "gfy_encode_hidden: stage %d outside 0..%d", tap, enc->layers);
+  if (enc->model_dtype == GFY_F16)
+    return launch_encode_f16(enc, x, row_ptr, col, typ, n, e, out_rows, out,
+                             out_dtype, normalise, tap, ws, ws_bytes,
+                             (hipStream_t)stream);
+  return launch_encode_f32(enc, x, row_ptr, col, typ, n, e, out_rows, out,
+                           out_dtype, normalise, tap, ws, ws_bytes,
+                           (hipStream_t)stream);
+}
+
+int gfy_encode(gfy_encoder* enc, const float* x, const int32_t* row_ptr,
+               const int32_t* col, const uint8_t* typ, int64_t n, int64_t e,
+               const int32_t* out_rows, void* out, int out_dtype, int normalise,
+               void* ws, size_t ws_bytes, void* stream) {
+  return encode_common(enc, x, row_ptr, col, typ, n, e, out_rows, out, out_dtype,
+                       normalise, -1, ws, ws_bytes, stream);
+}
+
+int gfy_encode_hidden(gfy_encoder* enc, const float* x, const int32_t* row_ptr,
+                      const int32_t* col, const uint8_t* typ, int64_t n,
+                      int64_t e, int stage, void* out, void* ws, size_t ws_bytes,
+                      void* stream) {
+  GFY_REQUIRE(stage >= 0, GFY_ERR_INVALID, "gfy_encode_hidden: negative stage");
+  return encode_common(enc, x, row_ptr, col, typ, n, e, nullptr, out,
+                       enc ? enc->model_dtype : GFY_F16, 0, stage, ws, ws_bytes,
+                       stream);
+}
+
+int gfy_pairwise_dense(const void* a, int64_t n, const void* b, int64_t m,
+                       int metric, float* out, void* stream) {
+  clear_error();
+  GFY_REQUIRE(a && b && out && n > 0 && m > 0, GFY_ERR_INVALID,
+              "gfy_pairwise_dense: bad arguments");
+  GFY_REQUIRE(metric == GFY_L2 || metric == GFY_COSINE, GFY_ERR_INVALID,
+              "gfy_pairwise_dense: unknown metric %d", metric);
+  return launch_pairwise_dense(a, n, b, m, metric, out, (hipStream_t)stream);
+}
+
+size_t gfy_pairwise_workspace_bytes(int64_t n, int64_t m) {
+  return pairwise_workspace_bytes(n < 1 ? 1 : n, m < 1 ? 1 : m);
+}
+
+int gfy_pairwise_nearest(const void* a, int64_t n, const void* b, int64_t m,
+                         int metric, int64_t exclude_offset, float* best_val,
+                         int32_t* best_idx, void* ws, size_t ws_bytes,
+                         void* stream) {
+  clear_error();
+  GFY_REQUIRE(a && b && best_val && best_idx && ws && n > 0 && m > 0 &&
+                  m < INT32_MAX,
+              GFY_ERR_INVALID, "gfy_pairwise_nearest: bad arguments");
+  GFY_REQUIRE(metric == GFY_L2 || metric == GFY_COSINE, GFY_ERR_INVALID,
+              "gfy_pairwise_nearest: unknown metric %d", metric);
+  return launch_pairwise_nearest(a, n, b, m, metric, exclude_offset, best_val,
+                                 best_idx, ws, ws_bytes, (hipStream_t)stream);
+}
+
+}  // extern "C"

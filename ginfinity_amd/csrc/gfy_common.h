@@ -1,0 +1,151 @@
+// Shared host/device helpers of libgfy (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/gfy.h"
+
+namespace gfy {
+
+// ---- per-thread error channel -------------------------------------------------
+void set_error(const char* fmt, ...);
+void clear_error();
+
+#define GFY_CHECK_HIP(expr)                                                    \
+  do {                                                                         \
+    hipError_t _e = (expr);                                                    \
+    if (_e != hipSuccess) {                                                    \
+      ::gfy::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                       __FILE__, __LINE__);                                    \
+      return GFY_ERR_HIP;                                                      \
+    }                                                                          \
+  } while (0)
+
+#define GFY_REQUIRE(cond, code, ...)  \
+  do {                                \
+    if (!(cond)) {                    \
+      ::gfy::set_error(__VA_ARGS__);  \
+      return (code);                  \
+    }                                 \
+  } while (0)
+
+// ---- model geometry compiled into the kernels -----------------------------------
+constexpr int kHidden = 128;   // data/model.json:12
+constexpr int kMlp = 256;      // 2 * hidden       (_model.py:34)
+constexpr int kInDim = 7;      // node features    (graph.py:91-93)
+constexpr int kOutDim = 128;
+constexpr int kMaxEdgeTypes = 16;
+constexpr int kMaxLayers = 8;
+
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- fp16 layer parameters on the device (see gine_f16.hip for the layouts) ------
+struct LayerF16 {
+  const f16* edge_table;  // [kMaxEdgeTypes][128]  R(W_edge[:,t] + b_edge), rows >= edge_dim zero
+  float scale;            // fp16 value R(1 + R(eps)) widened to fp32
+  const f16* w0_frag;     // mlp.0.weight in MFMA B-fragment order
+  const f16* b0;          // [256]
+  const float* bn_alpha;  // [256]  invstd * gamma          (fp32, from fp16-rounded buffers)
+  const float* bn_shift;  // [256]  beta - mean * alpha
+  const f16* w1_frag;     // mlp.4.weight in MFMA B-fragment order
+  const f16* b1;          // [128]
+  const f16* ln_gamma;    // [128]
+  const f16* ln_beta;     // [128]
+};
+
+struct HeadF16 {
+  const f16* wa_frag;  // head.0.weight fragments
+  const f16* ba;       // [128]
+  const f16* wb_frag;  // head.2.weight fragments
+  const f16* bb;       // [128]
+};
+
+struct ModelF16 {
+  const f16* w_in;  // [128][8] (k padded 7 -> 8 with zero)
+  const f16* b_in;  // [128]
+  LayerF16 layer[kMaxLayers];
+  HeadF16 head;
+};
+
+// ---- fp32 (full_precision) parameters: plain row-major fp32 on the device --------
+struct LayerF32 {
+  const float* edge_w;  // [128][edge_dim]
+  const float* edge_b;  // [128]
+  float eps;
+  const float* w0;  // [256][128]
+  const float* b0;
+  const float *bn_g, *bn_b, *bn_mean, *bn_var;
+  const float* w1;  // [128][256]
+  const float* b1;
+  const float *ln_g, *ln_b;
+};
+
+struct ModelF32 {
+  const float* w_in;  // [128][7]
+  const float* b_in;
+  LayerF32 layer[kMaxLayers];
+  const float *ha_w, *ha_b, *hb_w, *hb_b;
+};
+
+}  // namespace gfy
+
+struct gfy_encoder {
+  int device = 0;
+  int model_dtype = GFY_F16;
+  int layers = 0;
+  int edge_dim = 0;
+  int residual = 1;
+  void* device_blob = nullptr;  // one allocation holding every derived tensor
+  size_t device_blob_bytes = 0;
+  gfy::ModelF16 f16{};
+  gfy::ModelF32 f32{};
+};
+
+// ---- kernel launchers (one per .hip file) -------------------------------------------
+namespace gfy {
+
+int launch_build_csr(const int32_t* edge_index, const uint8_t* edge_types,
+                     int64_t n, int64_t e, int32_t* row_ptr, int32_t* col,
+                     uint8_t* typ, void* ws, size_t ws_bytes, hipStream_t s);
+size_t csr_workspace_bytes(int64_t n, int64_t e);
+
+int launch_encode_f16(const gfy_encoder* enc, const float* x,
+                      const int32_t* row_ptr, const int32_t* col,
+                      const uint8_t* typ, int64_t n, int64_t e,
+                      const int32_t* out_rows, void* out, int out_dtype,
+                      int normalise, int tap_stage, void* ws, size_t ws_bytes,
+                      hipStream_t s);
+size_t encode_f16_workspace_bytes(int64_t n, int64_t e);
+
+int launch_encode_f32(const gfy_encoder* enc, const float* x,
+                      const int32_t* row_ptr, const int32_t* col,
+                      const uint8_t* typ, int64_t n, int64_t e,
+                      const int32_t* out_rows, void* out, int out_dtype,
+                      int normalise, int tap_stage, void* ws, size_t ws_bytes,
+                      hipStream_t s);
+size_t encode_f32_workspace_bytes(int64_t n, int64_t e);
+
+int launch_pairwise_dense(const void* a, int64_t n, const void* b, int64_t m,
+                          int metric, float* out, hipStream_t s);
+int launch_pairwise_nearest(const void* a, int64_t n, const void* b, int64_t m,
+                            int metric, int64_t exclude_offset, float* best_val,
+                            int32_t* best_idx, void* ws, size_t ws_bytes,
+                            hipStream_t s);
+size_t pairwise_workspace_bytes(int64_t n, int64_t m);
+
+// W[n_out][k_in] (row-major fp16) -> MFMA 32x32x16 B-operand fragment order:
+// frag[(ntile * ksteps + ks) * 64 + lane][8] = W[32*ntile + (lane & 31)][16*ks + 8*(lane >> 5) + j]
+void pack_b_fragments(const f16* w, int n_out, int k_in, f16* frag);
+
+}  // namespace gfy

@@ -1,0 +1,540 @@
+// fp16-mode GINE encode for gfx950 (MI355X): input Linear, fused GINE layer,
+// head + float64 L2 normalise.
+//
+// Reference ops replaced (src/ginfinity):
+//   _model.py:67      input Linear(7,128)                 -> k_input_linear_f16
+//   _model.py:41-46   message / aggregate / (1+eps)x / MLP |
+//   _model.py:34-36   Linear-BatchNorm-ReLU-Linear         |-> k_gine_layer_f16
+//   _model.py:69-71   LayerNorm + residual                 |
+//   _model.py:72      head Linear-ReLU-Linear              |-> k_head_f16
+//   api.py:250-259    fp64 normalise, core rows, dtype     |
+//
+// Numerics contract (oracle/gine_numpy.py): every reference op
+// boundary rounds to fp16 in-register; arithmetic inside an op is fp32
+// (fp64 for LayerNorm moments and the final normalise).  v_pk_add_f16 /
+// v_pk_mul_f16 are used where "fp32 op then round" and the native fp16 op
+// agree exactly (sum/product of two fp16 values: 24 >= 2*11+2 bits).
+//
+// Layer kernel, one 512-thread workgroup (8 waves) per CU, persistent over
+// 64-node tiles; tiles are dealt so that each XCD owns a contiguous node range
+// (backbone / skip-2 neighbours then hit that XCD's L2):
+//   A  gather-sum   16 lanes x 16 B per node row, CSR in-edges in COO order,
+//                   fp32 accumulate, z -> LDS (fp16, XOR-swizzled 16-B chunks)
+//   B  GEMM1        U^T = W0 . Z^T on v_mfma_f32_32x32x16_f16, W0 fragments live
+//                   in registers for the whole launch; epilogue bias, round,
+//                   BatchNorm fma, round, ReLU -> LDS
+//   C  GEMM2        W^T = W1 . V^T, W1 fragments in registers; bias, round -> LDS
+//   D  LayerNorm    fp64 moments over 16 lanes, fma-fma affine, round, residual
+//                   add, 16-B coalesced store of the new hidden row
+// The node index sits on the MFMA lane (C^T form), so each lane's 4 consecutive
+// accumulator registers are 4 consecutive channels of one node: 8-byte LDS
+// writes, no transposition.
+#include "gfy_common.h"
+
+namespace gfy {
+namespace {
+
+constexpr int kTile = 64;       // nodes per tile
+constexpr int kThreads = 512;   // 8 waves, 2 per SIMD
+
+// ---- LDS map of the layer kernel (bytes) -----------------------------------------
+constexpr int kLdsZW = 0;                       // 64 x 256 B  z, later w
+constexpr int kLdsV = kLdsZW + kTile * 256;     // 64 x 512 B  v
+constexpr int kLdsTable = kLdsV + kTile * 512;  // 16 x 128 f16 edge table
+constexpr int kLdsB0 = kLdsTable + kMaxEdgeTypes * kHidden * 2;
+constexpr int kLdsAlpha = kLdsB0 + kMlp * 2;
+constexpr int kLdsShift = kLdsAlpha + kMlp * 4;
+constexpr int kLdsB1 = kLdsShift + kMlp * 4;
+constexpr int kLdsLayerBytes = kLdsB1 + kHidden * 2;
+
+// 16-byte chunk `chunk` of row `row`, XOR-swizzled so that the 16 lanes of one
+// ds_read_b128 lane group (16 distinct rows, same chunk) hit 16 different slots.
+__device__ __forceinline__ int off256(int row, int chunk) {
+  return row * 256 + ((chunk ^ (row & 15)) << 4);
+}
+__device__ __forceinline__ int off512(int row, int chunk) {
+  return row * 512 + ((chunk ^ (row & 15)) << 4);
+}
+
+__device__ __forceinline__ f32x16 mfma(f16x8 a, f16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f16x8 zero8() {
+  f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  return z;
+}
+
+// tiles owned by workgroup b: XCD (b & 7) owns tiles [xcd*tpx, (xcd+1)*tpx)
+struct TileWalk {
+  int tiles_per_xcd, slots_per_xcd, xcd, j;
+  __device__ TileWalk(int num_tiles)
+      : tiles_per_xcd((num_tiles + 7) >> 3),
+        slots_per_xcd(gridDim.x >> 3),
+        xcd(blockIdx.x & 7),
+        j(blockIdx.x >> 3) {}
+  __device__ int tile() const { return xcd * tiles_per_xcd + j; }
+  __device__ bool valid(int num_tiles) const {
+    return j < tiles_per_xcd && tile() < num_tiles;
+  }
+  __device__ void next() { j += slots_per_xcd; }
+};
+
+// ---------------------------------------------------------------------------------
+// input Linear: h0 = R(R(x) . Win^T + b)            (_model.py:67, api.py:237-238)
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_input_linear_f16(
+    const float* __restrict__ x, const f16* __restrict__ w_in /*[128][8]*/,
+    const f16* __restrict__ b_in, f16* __restrict__ h, int n) {
+  const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t node = item >> 4;
+  const int chunk = (int)(item & 15);
+  if (node >= n) return;
+  float xv[kInDim];
+#pragma unroll
+  for (int k = 0; k < kInDim; ++k) xv[k] = (float)(f16)x[node * kInDim + k];
+  f16x8 out;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int ch = chunk * 8 + c;
+    const f16x8 w = *reinterpret_cast<const f16x8*>(w_in + ch * 8);
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < kInDim; ++k) acc = __builtin_fmaf(xv[k], (float)w[k], acc);
+    out[c] = (f16)(acc + (float)b_in[ch]);
+  }
+  *reinterpret_cast<f16x8*>(h + node * kHidden + chunk * 8) = out;
+}
+
+// ---------------------------------------------------------------------------------
+// fused GINE layer
+// ---------------------------------------------------------------------------------
+template <bool kResidual>
+__global__ __launch_bounds__(kThreads, 2) void k_gine_layer_f16(
+    const LayerF16 p, const f16* __restrict__ h_in, f16* __restrict__ h_out,
+    const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
+    const uint8_t* __restrict__ typ, int n, int num_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const zw = smem + kLdsZW;
+  char* const vt = smem + kLdsV;
+  f16* const table = reinterpret_cast<f16*>(smem + kLdsTable);
+  f16* const b0s = reinterpret_cast<f16*>(smem + kLdsB0);
+  float* const alphas = reinterpret_cast<float*>(smem + kLdsAlpha);
+  float* const shifts = reinterpret_cast<float*>(smem + kLdsShift);
+  f16* const b1s = reinterpret_cast<f16*>(smem + kLdsB1);
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int r = lane & 31, hq = lane >> 5;
+  const int chunk = t & 15, rsub = t >> 4;  // gather / LayerNorm mapping
+
+  // per-launch constants -> LDS
+  for (int i = t; i < kMaxEdgeTypes * kHidden / 8; i += kThreads)
+    reinterpret_cast<f16x8*>(table)[i] =
+        reinterpret_cast<const f16x8*>(p.edge_table)[i];
+  if (t < kMlp / 8)
+    reinterpret_cast<f16x8*>(b0s)[t] = reinterpret_cast<const f16x8*>(p.b0)[t];
+  if (t < kMlp / 4) {
+    reinterpret_cast<f32x4*>(alphas)[t] = reinterpret_cast<const f32x4*>(p.bn_alpha)[t];
+    reinterpret_cast<f32x4*>(shifts)[t] = reinterpret_cast<const f32x4*>(p.bn_shift)[t];
+  }
+  if (t < kHidden / 8)
+    reinterpret_cast<f16x8*>(b1s)[t] = reinterpret_cast<const f16x8*>(p.b1)[t];
+
+  // weight fragments -> registers, kept for every tile of this workgroup
+  f16x8 w0f[8], w1f[16];
+  {
+    const f16x8* w0p = reinterpret_cast<const f16x8*>(p.w0_frag) + (wave * 8) * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) w0f[ks] = w0p[ks * 64];
+    const f16x8* w1p =
+        reinterpret_cast<const f16x8*>(p.w1_frag) + ((wave >> 1) * 16) * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) w1f[ks] = w1p[ks * 64];
+  }
+  const f16x8 gamma8 = reinterpret_cast<const f16x8*>(p.ln_gamma)[chunk];
+  const f16x8 beta8 = reinterpret_cast<const f16x8*>(p.ln_beta)[chunk];
+  const f16 scale16 = (f16)p.scale;
+  __syncthreads();
+
+  for (TileWalk walk(num_tiles); walk.valid(num_tiles); walk.next()) {
+    const int base = walk.tile() * kTile;
+    f16x8 hself[2];
+
+    // ---- A: gather-sum -> z --------------------------------------------------
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int row = pass * 32 + rsub;
+      const int node = base + row;
+      f16x8 z = zero8();
+      hself[pass] = zero8();
+      if (node < n) {
+        const int lo = row_ptr[node], hi = row_ptr[node + 1];
+        const f16x8 hs = *reinterpret_cast<const f16x8*>(
+            h_in + (size_t)node * kHidden + chunk * 8);
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        int e = lo;
+        for (; e + 1 < hi; e += 2) {  // two rows in flight
+          const int s0 = col[e], s1 = col[e + 1];
+          const int t0 = typ[e], t1 = typ[e + 1];
+          const f16x8 h0 = *reinterpret_cast<const f16x8*>(
+              h_in + (size_t)s0 * kHidden + chunk * 8);
+          const f16x8 h1 = *reinterpret_cast<const f16x8*>(
+              h_in + (size_t)s1 * kHidden + chunk * 8);
+          const f16x8 e0 = *reinterpret_cast<const f16x8*>(table + t0 * kHidden + chunk * 8);
+          const f16x8 e1 = *reinterpret_cast<const f16x8*>(table + t1 * kHidden + chunk * 8);
+          const f16x8 m0 = __builtin_elementwise_max(h0 + e0, zero8());
+          const f16x8 m1 = __builtin_elementwise_max(h1 + e1, zero8());
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += (float)m0[j];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += (float)m1[j];
+        }
+        if (e < hi) {
+          const int s0 = col[e];
+          const int t0 = typ[e];
+          const f16x8 h0 = *reinterpret_cast<const f16x8*>(
+              h_in + (size_t)s0 * kHidden + chunk * 8);
+          const f16x8 e0 = *reinterpret_cast<const f16x8*>(table + t0 * kHidden + chunk * 8);
+          const f16x8 m0 = __builtin_elementwise_max(h0 + e0, zero8());
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += (float)m0[j];
+        }
+        f16x8 agg;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) agg[j] = (f16)acc[j];   // ONE rounding of the fp32 sum
+        z = hs * scale16 + agg;   // R(R(s*h) + a): two fp16 ops (contraction is off)
+        hself[pass] = hs;
+      }
+      *reinterpret_cast<f16x8*>(zw + off256(row, chunk)) = z;
+    }
+    __syncthreads();
+
+    // ---- B: U^T = W0 . Z^T ; v = relu(R(BN(R(u + b0)))) -------------------------
+    {
+      f32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const f16x8 z0 = *reinterpret_cast<const f16x8*>(zw + off256(r, 2 * ks + hq));
+        const f16x8 z1 = *reinterpret_cast<const f16x8*>(zw + off256(32 + r, 2 * ks + hq));
+        acc0 = mfma(w0f[ks], z0, acc0);
+        acc1 = mfma(w0f[ks], z1, acc1);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = wave * 32 + 8 * g + 4 * hq;  // 4 consecutive channels
+        const f16x4 b0v = *reinterpret_cast<const f16x4*>(b0s + c0);
+        const f32x4 al = *reinterpret_cast<const f32x4*>(alphas + c0);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(shifts + c0);
+        f16x4 v0, v1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f16 u0 = (f16)(acc0[4 * g + i] + (float)b0v[i]);
+          const f16 u1 = (f16)(acc1[4 * g + i] + (float)b0v[i]);
+          const f16 y0 = (f16)__builtin_fmaf((float)u0, al[i], sh[i]);
+          const f16 y1 = (f16)__builtin_fmaf((float)u1, al[i], sh[i]);
+          v0[i] = y0 > (f16)0 ? y0 : (f16)0;
+          v1[i] = y1 > (f16)0 ? y1 : (f16)0;
+        }
+        *reinterpret_cast<f16x4*>(vt + off512(r, c0 >> 3) + hq * 8) = v0;
+        *reinterpret_cast<f16x4*>(vt + off512(32 + r, c0 >> 3) + hq * 8) = v1;
+      }
+    }
+    __syncthreads();
+
+    // ---- C: W^T = W1 . V^T ; w = R(acc + b1) --------------------------------------
+    {
+      const int nt = wave & 1, ct = wave >> 1;
+      f32x16 acc = {0};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const f16x8 v8 =
+            *reinterpret_cast<const f16x8*>(vt + off512(32 * nt + r, 2 * ks + hq));
+        acc = mfma(w1f[ks], v8, acc);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = ct * 32 + 8 * g + 4 * hq;
+        const f16x4 b1v = *reinterpret_cast<const f16x4*>(b1s + c0);
+        f16x4 wv;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wv[i] = (f16)(acc[4 * g + i] + (float)b1v[i]);
+        *reinterpret_cast<f16x4*>(zw + off256(32 * nt + r, c0 >> 3) + hq * 8) = wv;
+      }
+    }
+    __syncthreads();
+
+    // ---- D: LayerNorm, residual, store -----------------------------------------
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int row = pass * 32 + rsub;
+      const int node = base + row;
+      const f16x8 w8 = *reinterpret_cast<const f16x8*>(zw + off256(row, chunk));
+      float xf[8];
+      double sum = 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        xf[j] = (float)w8[j];
+        sum += (double)xf[j];
+      }
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) sum += __shfl_xor(sum, m, 64);
+      const double mean64 = sum * (1.0 / kHidden);
+      double sq = 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const double d = (double)xf[j] - mean64;
+        sq += d * d;
+      }
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) sq += __shfl_xor(sq, m, 64);
+      const float var = (float)(sq * (1.0 / kHidden));
+      const float mean = (float)mean64;
+      const float rstd = 1.0f / __builtin_sqrtf(var + 1e-5f);
+      const float offset = -rstd * mean;
+      f16x8 y;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        y[j] = (f16)__builtin_fmaf(__builtin_fmaf(xf[j], rstd, offset),
+                                   (float)gamma8[j], (float)beta8[j]);
+      const f16x8 hn = kResidual ? (hself[pass] + y) : y;
+      if (node < n)
+        *reinterpret_cast<f16x8*>(h_out + (size_t)node * kHidden + chunk * 8) = hn;
+    }
+    __syncthreads();  // zw is rewritten by the next tile's gather
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// head + normalise
+// ---------------------------------------------------------------------------------
+// double -> fp16 with ONE rounding (numpy's astype(float16) from float64):
+// round to fp32 toward zero with a sticky bit (round-to-odd), then RNE to fp16.
+__device__ __forceinline__ f16 f64_to_f16_rne(double x) {
+  float f = (float)x;  // RNE
+  const double back = (double)f;
+  if (back != x) {
+    uint32_t bits = __float_as_uint(f);
+    if (__builtin_fabs(back) > __builtin_fabs(x)) bits -= 1u;  // toward zero
+    bits |= 1u;                                                  // sticky
+    f = __uint_as_float(bits);
+  }
+  return (f16)f;
+}
+
+template <typename OutT>
+__device__ __forceinline__ void store8(OutT* dst, const double (&v)[8]);
+template <>
+__device__ __forceinline__ void store8<f16>(f16* dst, const double (&v)[8]) {
+  f16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = f64_to_f16_rne(v[j]);
+  *reinterpret_cast<f16x8*>(dst) = o;
+}
+template <>
+__device__ __forceinline__ void store8<float>(float* dst, const double (&v)[8]) {
+  f32x4 a, b;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    a[j] = (float)v[j];
+    b[j] = (float)v[4 + j];
+  }
+  reinterpret_cast<f32x4*>(dst)[0] = a;
+  reinterpret_cast<f32x4*>(dst)[1] = b;
+}
+template <>
+__device__ __forceinline__ void store8<double>(double* dst, const double (&v)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dst[j] = v[j];
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(kThreads, 2) void k_head_f16(
+    const HeadF16 p, const f16* __restrict__ h, const int32_t* __restrict__ out_rows,
+    OutT* __restrict__ out, int n, int num_tiles, int normalise) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const ht = smem;                // 64 x 256 B: h, later o
+  char* const tt = smem + kTile * 256;  // 64 x 256 B: t
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int r = lane & 31, hq = lane >> 5;
+  const int chunk = t & 15, rsub = t >> 4;
+  const int nt = wave & 1, ct = wave >> 1;
+
+  f16x8 waf[8], wbf[8];
+  {
+    const f16x8* wa = reinterpret_cast<const f16x8*>(p.wa_frag) + (ct * 8) * 64 + lane;
+    const f16x8* wb = reinterpret_cast<const f16x8*>(p.wb_frag) + (ct * 8) * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      waf[ks] = wa[ks * 64];
+      wbf[ks] = wb[ks * 64];
+    }
+  }
+  f16x4 bav[4], bbv[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int c0 = ct * 32 + 8 * g + 4 * hq;
+    bav[g] = *reinterpret_cast<const f16x4*>(p.ba + c0);
+    bbv[g] = *reinterpret_cast<const f16x4*>(p.bb + c0);
+  }
+
+  for (TileWalk walk(num_tiles); walk.valid(num_tiles); walk.next()) {
+    const int base = walk.tile() * kTile;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int row = pass * 32 + rsub;
+      const int node = base + row;
+      f16x8 v = zero8();
+      if (node < n)
+        v = *reinterpret_cast<const f16x8*>(h + (size_t)node * kHidden + chunk * 8);
+      *reinterpret_cast<f16x8*>(ht + off256(row, chunk)) = v;
+    }
+    __syncthreads();
+    {  // t = relu(R(h . Wa^T + ba))                         (_model.py:61-62)
+      f32x16 acc = {0};
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+        acc = mfma(waf[ks],
+                   *reinterpret_cast<const f16x8*>(ht + off256(32 * nt + r, 2 * ks + hq)),
+                   acc);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = ct * 32 + 8 * g + 4 * hq;
+        f16x4 tv;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f16 u = (f16)(acc[4 * g + i] + (float)bav[g][i]);
+          tv[i] = u > (f16)0 ? u : (f16)0;
+        }
+        *reinterpret_cast<f16x4*>(tt + off256(32 * nt + r, c0 >> 3) + hq * 8) = tv;
+      }
+    }
+    __syncthreads();
+    {  // o = R(t . Wb^T + bb)                               (_model.py:63)
+      f32x16 acc = {0};
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+        acc = mfma(wbf[ks],
+                   *reinterpret_cast<const f16x8*>(tt + off256(32 * nt + r, 2 * ks + hq)),
+                   acc);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = ct * 32 + 8 * g + 4 * hq;
+        f16x4 ov;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ov[i] = (f16)(acc[4 * g + i] + (float)bbv[g][i]);
+        *reinterpret_cast<f16x4*>(ht + off256(32 * nt + r, c0 >> 3) + hq * 8) = ov;
+      }
+    }
+    __syncthreads();
+    // float64 L2 normalise, single rounding to the output dtype (api.py:250-259)
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int row = pass * 32 + rsub;
+      const int node = base + row;
+      const f16x8 o8 = *reinterpret_cast<const f16x8*>(ht + off256(row, chunk));
+      double v[8];
+      double ss = 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[j] = (double)(float)o8[j];
+        ss += v[j] * v[j];
+      }
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) ss += __shfl_xor(ss, m, 64);
+      if (normalise) {
+        const double nrm = __builtin_sqrt(ss);
+        const double den = nrm > 1e-12 ? nrm : 1e-12;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] / den;
+      }
+      if (node < n) {
+        const int dest = out_rows ? out_rows[node] : node;
+        if (dest >= 0) store8<OutT>(out + (size_t)dest * kOutDim + chunk * 8, v);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_copy_rows_f16(const f16* __restrict__ src,
+                                                       f16* __restrict__ dst,
+                                                       int64_t chunks) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < chunks; i += stride)
+    reinterpret_cast<f16x8*>(dst)[i] = reinterpret_cast<const f16x8*>(src)[i];
+}
+
+int persistent_grid(int num_tiles) {
+  int g = num_tiles < 256 ? num_tiles : 256;
+  g = (g + 7) & ~7;  // whole XCD rounds (TileWalk divides by 8)
+  return g < 8 ? 8 : g;
+}
+
+}  // namespace
+
+size_t encode_f16_workspace_bytes(int64_t n, int64_t /*e*/) {
+  return 2 * align_up((size_t)n * kHidden * sizeof(f16), 256);
+}
+
+int launch_encode_f16(const gfy_encoder* enc, const float* x,
+                      const int32_t* row_ptr, const int32_t* col,
+                      const uint8_t* typ, int64_t n, int64_t e,
+                      const int32_t* out_rows, void* out, int out_dtype,
+                      int normalise, int tap_stage, void* ws, size_t ws_bytes,
+                      hipStream_t s) {
+  (void)e;
+  const size_t need = encode_f16_workspace_bytes(n, e);
+  GFY_REQUIRE(ws_bytes >= need, GFY_ERR_WORKSPACE,
+              "gfy_encode: workspace %zu < required %zu", ws_bytes, need);
+  f16* ha = (f16*)ws;
+  f16* hb = (f16*)((char*)ws + need / 2);
+  const int num_tiles = (int)((n + kTile - 1) / kTile);
+  const int grid = persistent_grid(num_tiles);
+
+  const int64_t items = n * 16;
+  k_input_linear_f16<<<(int)((items + 255) / 256), 256, 0, s>>>(
+      x, enc->f16.w_in, enc->f16.b_in, ha, (int)n);
+  const int stop = tap_stage >= 0 ? tap_stage : enc->layers;
+  for (int l = 0; l < stop; ++l) {
+    if (enc->residual)
+      k_gine_layer_f16<true><<<grid, kThreads, kLdsLayerBytes, s>>>(
+          enc->f16.layer[l], ha, hb, row_ptr, col, typ, (int)n, num_tiles);
+    else
+      k_gine_layer_f16<false><<<grid, kThreads, kLdsLayerBytes, s>>>(
+          enc->f16.layer[l], ha, hb, row_ptr, col, typ, (int)n, num_tiles);
+    f16* sw = ha;
+    ha = hb;
+    hb = sw;
+  }
+  if (tap_stage >= 0) {
+    const int64_t chunks = n * 16;
+    int g = (int)((chunks + 255) / 256);
+    k_copy_rows_f16<<<g > 2048 ? 2048 : g, 256, 0, s>>>(ha, (f16*)out, chunks);
+    GFY_CHECK_HIP(hipGetLastError());
+    return GFY_OK;
+  }
+  const int head_lds = 2 * kTile * 256;
+  switch (out_dtype) {
+    case GFY_F16:
+      k_head_f16<f16><<<grid, kThreads, head_lds, s>>>(
+          enc->f16.head, ha, out_rows, (f16*)out, (int)n, num_tiles, normalise);
+      break;
+    case GFY_F32:
+      k_head_f16<float><<<grid, kThreads, head_lds, s>>>(
+          enc->f16.head, ha, out_rows, (float*)out, (int)n, num_tiles, normalise);
+      break;
+    default:
+      k_head_f16<double><<<grid, kThreads, head_lds, s>>>(
+          enc->f16.head, ha, out_rows, (double*)out, (int)n, num_tiles, normalise);
+  }
+  GFY_CHECK_HIP(hipGetLastError());
+  return GFY_OK;
+}
+
+}  // namespace gfy

@@ -1,0 +1,184 @@
+"""Device-side driver of the encode hot path: owns the gfy_encoder handle and
+moves one micro-batch through CSR build → GINE forward → normalise.
+
+This is the counterpart of the body of ``Ginfinity._run_graph_shard``
+(reference: src/ginfinity/api.py:236-252).  PyTorch is used for device memory,
+streams and H2D/D2H copies only; every arithmetic step is a libgfy kernel.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _native as native
+
+_TORCH_OF_NUMPY = {np.dtype(np.float16): (torch.float16, native.GFY_F16),
+                   np.dtype(np.float32): (torch.float32, native.GFY_F32),
+                   np.dtype(np.float64): (torch.float64, native.GFY_F64)}
+_GFY_OF_TORCH = {torch.float16: native.GFY_F16, torch.float32: native.GFY_F32,
+                 torch.float64: native.GFY_F64}
+EMBEDDING_DIM = 128
+
+
+def device_output_dtype(embedding_dtype: np.dtype) -> tuple[torch.dtype, int, bool]:
+    """(torch dtype, gfy code, exact) for a requested numpy embedding dtype.
+    Float kinds the kernels do not write directly are produced as float64 on
+    the device and cast on the host — the reference's own order of operations
+    (api.py:250-259: float64 normalise, then ``astype``)."""
+    key = np.dtype(embedding_dtype)
+    if key in _TORCH_OF_NUMPY:
+        return (*_TORCH_OF_NUMPY[key], True)
+    return torch.float64, native.GFY_F64, False
+
+
+@dataclass
+class DeviceCsr:
+    row_ptr: torch.Tensor   # int32 [N+1]
+    col: torch.Tensor       # int32 [E]
+    typ: torch.Tensor       # uint8 [E]
+    nodes: int
+    edges: int
+
+
+def _ptr(tensor: torch.Tensor | None) -> int | None:
+    return None if tensor is None else tensor.data_ptr()
+
+
+class DeviceEncoder:
+    """One gfy_encoder on one GPU.  Not thread-safe (docs/OPERATIONS.md:43-47
+    of the reference: serialized inference per instance)."""
+
+    def __init__(self, weight_pack: bytes, *, full_precision: bool,
+                 device: torch.device) -> None:
+        self._lib = native.library()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("DeviceEncoder needs a HIP ('cuda') device")
+        index = (self.device.index if self.device.index is not None
+                 else torch.cuda.current_device())
+        self.device = torch.device("cuda", index)
+        self.full_precision = bool(full_precision)
+        self.model_dtype = torch.float32 if full_precision else torch.float16
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            torch.empty(1, device=self.device)   # make sure the HIP context is live
+            native.check(self._lib.gfy_encoder_create(
+                weight_pack, len(weight_pack),
+                native.GFY_F32 if full_precision else native.GFY_F16,
+                index, ctypes.byref(handle)), "gfy_encoder_create")
+        self._handle = handle
+        self._workspace: torch.Tensor | None = None
+
+    # -- lifetime ---------------------------------------------------------------
+    def close(self) -> None:
+        handle, self._handle = getattr(self, "_handle", None), None
+        if handle:
+            self._lib.gfy_encoder_destroy(handle)
+
+    def __del__(self) -> None:  # pragma: no cover - interpreter shutdown order
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers ------------------------------------------------------------------
+    def _scratch(self, nbytes: int) -> torch.Tensor:
+        if self._workspace is None or self._workspace.numel() < nbytes:
+            self._workspace = torch.empty(
+                max(nbytes, 1 << 20), dtype=torch.uint8, device=self.device)
+        return self._workspace
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    # -- kernels ----------------------------------------------------------------------
+    def build_csr(self, edge_index: torch.Tensor, edge_types: torch.Tensor,
+                  nodes: int) -> DeviceCsr:
+        """COO (int32 [2,E], uint8 [E]) → destination-major CSR on the device."""
+        edges = int(edge_types.numel())
+        assert edge_index.dtype == torch.int32 and edge_index.is_contiguous()
+        assert edge_types.dtype == torch.uint8 and edge_types.is_contiguous()
+        assert tuple(edge_index.shape) == (2, edges)
+        with torch.cuda.device(self.device):
+            row_ptr = torch.empty(nodes + 1, dtype=torch.int32, device=self.device)
+            col = torch.empty(max(edges, 1), dtype=torch.int32, device=self.device)
+            typ = torch.empty(max(edges, 1), dtype=torch.uint8, device=self.device)
+            need = self._lib.gfy_csr_workspace_bytes(nodes, edges)
+            scratch = self._scratch(need)
+            native.check(self._lib.gfy_build_csr(
+                _ptr(edge_index) if edges else None,
+                _ptr(edge_types) if edges else None, nodes, edges,
+                _ptr(row_ptr), _ptr(col), _ptr(typ), _ptr(scratch),
+                scratch.numel(), self._stream()), "gfy_build_csr")
+        return DeviceCsr(row_ptr, col, typ, nodes, edges)
+
+    def encode(self, node_features: torch.Tensor, csr: DeviceCsr, *,
+               out_rows: torch.Tensor | None = None,
+               n_out: int | None = None,
+               out_dtype: torch.dtype = torch.float16,
+               normalise: bool = True,
+               out: torch.Tensor | None = None) -> torch.Tensor:
+        """GINE forward (+ float64 L2 normalise) → [n_out, 128] on the device."""
+        nodes = csr.nodes
+        assert node_features.dtype == torch.float32 and node_features.is_contiguous()
+        assert node_features.shape[0] == nodes
+        rows = nodes if n_out is None else int(n_out)
+        with torch.cuda.device(self.device):
+            if out is None:
+                out = torch.empty((rows, EMBEDDING_DIM), dtype=out_dtype,
+                                  device=self.device)
+            assert out.is_contiguous() and out.shape == (rows, EMBEDDING_DIM)
+            need = self._lib.gfy_encode_workspace_bytes(
+                self._handle, nodes, csr.edges)
+            scratch = self._scratch(need)
+            native.check(self._lib.gfy_encode(
+                self._handle, _ptr(node_features), _ptr(csr.row_ptr),
+                _ptr(csr.col), _ptr(csr.typ), nodes, csr.edges, _ptr(out_rows),
+                _ptr(out), _GFY_OF_TORCH[out.dtype], 1 if normalise else 0,
+                _ptr(scratch), scratch.numel(), self._stream()), "gfy_encode")
+        return out
+
+    def hidden(self, node_features: torch.Tensor, csr: DeviceCsr,
+               stage: int) -> torch.Tensor:
+        """Parity tap: hidden state after ``stage`` (0 = input Linear,
+        l+1 = after layer l), [N,128] in the model dtype."""
+        with torch.cuda.device(self.device):
+            out = torch.empty((csr.nodes, EMBEDDING_DIM), dtype=self.model_dtype,
+                              device=self.device)
+            need = self._lib.gfy_encode_workspace_bytes(
+                self._handle, csr.nodes, csr.edges)
+            scratch = self._scratch(need)
+            native.check(self._lib.gfy_encode_hidden(
+                self._handle, _ptr(node_features), _ptr(csr.row_ptr),
+                _ptr(csr.col), _ptr(csr.typ), csr.nodes, csr.edges, stage,
+                _ptr(out), _ptr(scratch), scratch.numel(), self._stream()),
+                "gfy_encode_hidden")
+        return out
+
+    # -- one micro-batch, host arrays in → device embeddings out ----------------------
+    def encode_arrays(self, node_features: np.ndarray, edge_index: np.ndarray,
+                      edge_types: np.ndarray, node_roles: np.ndarray | None,
+                      *, out_dtype: torch.dtype = torch.float16,
+                      normalise: bool = True) -> torch.Tensor:
+        """Host arrays of one shard slice → [core_nodes, 128] device tensor.
+        Context nodes (role != 0) take part in message passing and are dropped
+        in the head kernel's store (api.py:253-260)."""
+        nodes = int(node_features.shape[0])
+        out_rows = None
+        n_out = nodes
+        if node_roles is not None:
+            core = node_roles == 0
+            n_out = int(np.count_nonzero(core))
+            if n_out != nodes:
+                rows = np.cumsum(core, dtype=np.int32) - np.int32(1)
+                rows[~core] = -1
+                out_rows = torch.from_numpy(rows).to(self.device)
+        x = torch.from_numpy(np.ascontiguousarray(node_features)).to(self.device)
+        ei = torch.from_numpy(np.ascontiguousarray(edge_index)).to(self.device)
+        et = torch.from_numpy(np.ascontiguousarray(edge_types)).to(self.device)
+        csr = self.build_csr(ei, et, nodes)
+        return self.encode(x, csr, out_rows=out_rows, n_out=n_out,
+                           out_dtype=out_dtype, normalise=normalise)

@@ -1,0 +1,155 @@
+/* gfy.h — C ABI of the MI355X (gfx950) GINE encode / embedding-distance library.
+ *
+ * This is the drop-in boundary for the hot path of nicoaira/GINFINITY.  The
+ * reference has no FFI: its boundary is the Python seam
+ *     Ginfinity._run_graph_shard(shard, embedding_dtype)      src/ginfinity/api.py:232-260
+ * called from encode_graphs (api.py:227-228).  Every entry point below names
+ * the reference lines it replaces.  INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C types only; all array arguments are DEVICE pointers unless the
+ *     name ends in _host; the caller owns every buffer it passes in;
+ *   - every function that launches work takes a hipStream_t as `void* stream`
+ *     and only ENQUEUES: no hidden synchronisation, no allocation (graph-
+ *     capturable); scratch memory is caller-provided (`workspace`), sized by
+ *     the matching *_workspace_bytes query;
+ *   - return value: 0 = GFY_OK, otherwise an error code; the message is kept
+ *     per host thread and read with gfy_last_error().  The library never
+ *     aborts.  (Python shim maps codes to ValueError / RuntimeError —
+ *     reference error conventions: api.py:70-76,197-210.)
+ *   - a gfy_encoder handle is not thread-safe ("a loaded instance is safe for
+ *     serialized inference", docs/OPERATIONS.md:43-47).
+ */
+#ifndef GFY_H_
+#define GFY_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GFY_ABI_VERSION 1
+
+enum gfy_status {
+  GFY_OK = 0,
+  GFY_ERR_INVALID = 1,     /* bad argument / malformed weight pack            */
+  GFY_ERR_UNSUPPORTED = 2, /* architecture not compiled in (hidden != 128 …) */
+  GFY_ERR_HIP = 3,         /* a HIP runtime call failed                       */
+  GFY_ERR_WORKSPACE = 4    /* workspace too small                             */
+};
+
+enum gfy_dtype { GFY_F16 = 0, GFY_F32 = 1, GFY_F64 = 2 };
+
+enum gfy_metric { GFY_L2 = 0, GFY_COSINE = 1 };
+
+typedef struct gfy_encoder gfy_encoder;
+
+/* Last error message of the calling host thread ("" if none). */
+const char* gfy_last_error(void);
+int gfy_abi_version(void);
+
+/* ---- weight pack -----------------------------------------------------------
+ * One little-endian blob: a 32-byte header followed by float32 tensors in
+ * checkpoint order, row-major as torch stores them ([out_features][in_features]).
+ *
+ *   uint32 magic 'GFY1' (0x31594647), uint32 version (1), uint32 in_dim (7),
+ *   uint32 hidden (128), uint32 layers (4), uint32 edge_dim (10),
+ *   uint32 out_dim (128), uint32 flags (bit0 = residual)
+ *   input.weight[hidden][in_dim]  input.bias[hidden]
+ *   for l in 0..layers-1:
+ *     convs.l.eps[1]
+ *     convs.l.edge_lin.weight[hidden][edge_dim]  convs.l.edge_lin.bias[hidden]
+ *     convs.l.mlp.0.weight[2h][h]  convs.l.mlp.0.bias[2h]
+ *     convs.l.mlp.1.weight[2h] .bias[2h] .running_mean[2h] .running_var[2h]
+ *     convs.l.mlp.4.weight[h][2h]  convs.l.mlp.4.bias[h]
+ *     norms.l.weight[h]  norms.l.bias[h]
+ *   head.0.weight[h][h] head.0.bias[h] head.2.weight[out][h] head.2.bias[out]
+ * (reference: src/ginfinity/_model.py:29-63). */
+size_t gfy_weight_pack_bytes(uint32_t in_dim, uint32_t hidden, uint32_t layers,
+                             uint32_t edge_dim, uint32_t out_dim);
+
+/* Build an encoder on HIP device `device` from a HOST weight pack.
+ * model_dtype = GFY_F16 reproduces `model.half()` (api.py:111-112: parameters
+ * and BatchNorm buffers rounded to fp16, fp16 activations with fp32 internals);
+ * GFY_F32 is `full_precision=True`.  Replaces api.py:101-112 (module build,
+ * .to(device), .half()).  Synchronous (uploads weights). */
+int gfy_encoder_create(const void* weight_pack_host, size_t bytes,
+                       int model_dtype, int device, gfy_encoder** out);
+void gfy_encoder_destroy(gfy_encoder* encoder);
+
+/* ---- COO -> CSR ------------------------------------------------------------
+ * Destination-major CSR of a shard's edges, edges of one destination kept in
+ * their COO order (a stable counting sort; integer work, bit-exact, run-to-run
+ * deterministic).  Replaces the int64 widening + index_select/index_add_
+ * addressing of api.py:239-242 and _model.py:41-45.
+ *   edge_index  int32 [2][E]   row 0 = source, row 1 = destination (graph.py:306-308)
+ *   edge_types  uint8 [E]
+ *   row_ptr     int32 [N+1]    out
+ *   col         int32 [E]      out: source node of each in-edge
+ *   typ         uint8 [E]      out: edge type of each in-edge                */
+size_t gfy_csr_workspace_bytes(int64_t n_nodes, int64_t n_edges);
+int gfy_build_csr(const int32_t* edge_index, const uint8_t* edge_types,
+                  int64_t n_nodes, int64_t n_edges, int32_t* row_ptr,
+                  int32_t* col, uint8_t* typ, void* workspace,
+                  size_t workspace_bytes, void* stream);
+
+/* ---- encode ------------------------------------------------------------------
+ * GINEEncoder.forward (+ optional float64 L2 normalise) for one micro-batch:
+ * input Linear, `layers` x (GINE message/aggregate/update, BatchNorm MLP,
+ * LayerNorm, residual), 2-layer head.  Replaces api.py:237-252 and
+ * _model.py:39-46,65-72.
+ *   node_features float32 [N][in_dim]          (graph.py:302-305)
+ *   row_ptr/col/typ                            from gfy_build_csr
+ *   out_rows      int32 [N] or NULL: output row of node i, -1 = drop the node
+ *                 (context nodes of sliced graphs, api.py:253-260); NULL = i
+ *   out           [n_out_rows][out_dim] of out_dtype (f16 / f32 / f64)
+ *   normalise     1: out = o / max(||o||_2, 1e-12) computed in float64 and
+ *                 rounded once to out_dtype (api.py:250-252,258-259);
+ *                 0: raw head output o                                          */
+size_t gfy_encode_workspace_bytes(const gfy_encoder* encoder, int64_t n_nodes,
+                                  int64_t n_edges);
+int gfy_encode(gfy_encoder* encoder, const float* node_features,
+               const int32_t* row_ptr, const int32_t* col, const uint8_t* typ,
+               int64_t n_nodes, int64_t n_edges, const int32_t* out_rows,
+               void* out, int out_dtype, int normalise, void* workspace,
+               size_t workspace_bytes, void* stream);
+
+/* Debug/parity tap: copy the hidden state after `stage` into `out`
+ * ([N][hidden] in the model dtype): stage 0 = input Linear, l+1 = after layer l.
+ * Same arguments as gfy_encode; used by the stage-by-stage parity tests. */
+int gfy_encode_hidden(gfy_encoder* encoder, const float* node_features,
+                      const int32_t* row_ptr, const int32_t* col,
+                      const uint8_t* typ, int64_t n_nodes, int64_t n_edges,
+                      int stage, void* out, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* ---- all-pairs distance over 128-d embeddings ----------------------------------
+ * No reference symbol (the aligner lives in the external `ginfinity-sw`;
+ * only parameters are exported: api.py:47-50, data/alignment.json:6) — defined
+ * here as D_ij = sqrt(max(|a_i|^2 + |b_j|^2 - 2 a_i.b_j, 0)) (GFY_L2) or
+ * S_ij = a_i.b_j / (|a_i||b_j|) (GFY_COSINE); fp16 inputs, fp32 accumulation
+ * on the matrix cores.
+ *   a [n][128] fp16, b [m][128] fp16.                                           */
+
+/* Dense block: out float32 [n][m]  (small blocks only: n*m*4 bytes). */
+int gfy_pairwise_dense(const void* a, int64_t n, const void* b, int64_t m,
+                       int metric, float* out, void* stream);
+
+/* Fused row reduction, the N x M matrix is never materialised:
+ *   best_val float32 [n], best_idx int32 [n]: nearest b-row of each a-row
+ *   (smallest distance for GFY_L2, largest similarity for GFY_COSINE; ties ->
+ *   lowest index).  exclude_offset >= 0 skips the pair (i, i + exclude_offset)
+ *   — "self" when b is a with a row offset; -1 excludes nothing.               */
+size_t gfy_pairwise_workspace_bytes(int64_t n, int64_t m);
+int gfy_pairwise_nearest(const void* a, int64_t n, const void* b, int64_t m,
+                         int metric, int64_t exclude_offset, float* best_val,
+                         int32_t* best_idx, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GFY_H_ */
