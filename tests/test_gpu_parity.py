@@ -1,0 +1,239 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle and against
+fixtures recorded from the genuine reference.
+
+Tolerances (BASELINE.json north_star): integer/index work bit-exact; fp16-model
+embeddings within 1e-3, fp32-model embeddings within 1e-6 of the reference's
+own encode on identical shards (unit-norm rows, max-abs).
+"""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+F16_TOL = 1e-3
+F32_TOL = 1e-6
+
+
+def _maxabs(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())
+
+
+def _device_inputs(encoder, shard):
+    import torch
+    dev = encoder._engine.device
+    x = torch.from_numpy(np.ascontiguousarray(shard.node_features)).to(dev)
+    ei = torch.from_numpy(np.ascontiguousarray(shard.edge_index)).to(dev)
+    et = torch.from_numpy(np.ascontiguousarray(shard.edge_types)).to(dev)
+    return x, ei, et
+
+
+# ---- integer path ---------------------------------------------------------------
+
+@pytest.mark.parametrize("case", ["example8", "rouskin_mb0", "arbitrary", "empty_edges",
+                                   "synthetic"])
+def test_csr_bit_exact(case, gpu_encoder, rouskin_shard):
+    import torch
+    from oracle import gine_numpy as G
+    from ginfinity_amd import GraphBuilder, RNA, synthetic
+    if case == "example8":
+        shard = GraphBuilder().build_shard([RNA("example", "ACGUACGU", "((....))")])
+    elif case == "rouskin_mb0":
+        shard = rouskin_shard.slice(0, 413)
+    elif case == "arbitrary":
+        shard = synthetic.arbitrary_shard(0)
+    elif case == "synthetic":
+        shard = synthetic.roofline_shard(3)
+    else:
+        shard = GraphBuilder().build_shard([RNA("a", "A", "."), RNA("b", "C", ".")])
+    _, ei, et = _device_inputs(gpu_encoder, shard)
+    csr = gpu_encoder._engine.build_csr(ei, et, shard.node_count)
+    torch.cuda.synchronize()
+    row_ptr, col, typ = G.build_csr(shard.edge_index, shard.edge_types, shard.node_count)
+    e = shard.edge_count
+    np.testing.assert_array_equal(csr.row_ptr.cpu().numpy(), row_ptr)
+    np.testing.assert_array_equal(csr.col.cpu().numpy()[:e], col)
+    np.testing.assert_array_equal(csr.typ.cpu().numpy()[:e], typ)
+
+
+def test_csr_hub_rows_and_determinism(gpu_encoder):
+    """One destination with thousands of in-edges (worklist path) + run-to-run
+    identical output."""
+    import torch
+    from oracle import gine_numpy as G
+    rng = np.random.default_rng(11)
+    n, e = 5000, 60000
+    edge_index = rng.integers(0, n, size=(2, e)).astype(np.int32)
+    edge_index[1, :7000] = 17
+    edge_index[1, 7000:7040] = 99
+    perm = rng.permutation(e)
+    edge_index = np.ascontiguousarray(edge_index[:, perm])
+    types = rng.integers(0, 10, size=e).astype(np.uint8)
+    dev = gpu_encoder._engine.device
+    ei = torch.from_numpy(edge_index).to(dev)
+    et = torch.from_numpy(types).to(dev)
+    first = gpu_encoder._engine.build_csr(ei, et, n)
+    second = gpu_encoder._engine.build_csr(ei, et, n)
+    row_ptr, col, typ = G.build_csr(edge_index, types, n)
+    for got in (first, second):
+        np.testing.assert_array_equal(got.row_ptr.cpu().numpy(), row_ptr)
+        np.testing.assert_array_equal(got.col.cpu().numpy()[:e], col)
+        np.testing.assert_array_equal(got.typ.cpu().numpy()[:e], typ)
+
+
+# ---- stage-by-stage against the oracle ----------------------------------------------
+
+def test_hidden_stages_match_oracle(gpu_encoder, oracle_weights, rouskin_shard):
+    from oracle import gine_numpy as G
+    shard = rouskin_shard.slice(0, 64)
+    trace = {}
+    G.forward_f16(oracle_weights.half(), shard.node_features, shard.edge_index,
+                  shard.edge_types, trace)
+    x, ei, et = _device_inputs(gpu_encoder, shard)
+    engine = gpu_encoder._engine
+    csr = engine.build_csr(ei, et, shard.node_count)
+    h0 = engine.hidden(x, csr, 0).cpu().numpy()
+    np.testing.assert_array_equal(h0, trace["h0"])           # exact: K=7, exact products
+    for layer in range(4):
+        got = engine.hidden(x, csr, layer + 1).cpu().numpy()
+        want = trace[f"l{layer}.h"]
+        mismatch = float(np.mean(got != want))
+        print(f"layer {layer}: mismatch {mismatch:.4f} maxabs {_maxabs(got, want):.4f}")
+        # only accumulation-order one-ulp flips may differ, and they compound
+        # through the layers (layer 0 alone: ~2 %)
+        assert mismatch < (0.03, 0.10, 0.25, 0.40)[layer], (layer, mismatch)
+        assert _maxabs(got, want) < 0.05, layer
+    raw = engine.encode(x, csr, normalise=False).cpu().numpy()
+    assert _maxabs(raw, trace["o"]) < 0.02
+
+
+def test_example8_matches_reference_golden(gpu_encoder, golden):
+    from ginfinity_amd import RNA
+    g = golden("example8.npz")
+    record = RNA("example", "ACGUACGU", "((....))")
+    out = gpu_encoder.encode(record)
+    assert out.shape == (8, 128) and out.dtype == np.float16
+    assert _maxabs(out, g["out.m16.float16"]) <= F16_TOL
+    again = gpu_encoder.encode(record)
+    np.testing.assert_array_equal(out, again)              # deterministic
+    norms = np.linalg.norm(out.astype(np.float64), axis=1)
+    np.testing.assert_allclose(norms, 1.0, atol=1e-3)
+    for dtype in ("float32", "float64"):
+        got = gpu_encoder.encode(record, embedding_dtype=dtype)
+        assert got.dtype == np.dtype(dtype)
+        assert _maxabs(got, g[f"out.m16.{dtype}"]) <= F16_TOL
+        np.testing.assert_allclose(np.linalg.norm(got.astype(np.float64), axis=1),
+                                   1.0, atol=1e-6)
+
+
+def test_rouskin64_matches_reference_golden(gpu_encoder, golden, rouskin_shard):
+    g = golden("rouskin64.npz")
+    outputs = gpu_encoder.encode_graphs(rouskin_shard.slice(0, 64))
+    got = np.concatenate(outputs)
+    assert got.shape == g["out.m16"].shape
+    assert _maxabs(got, g["out.m16"]) <= F16_TOL
+    assert [o.shape[0] for o in outputs] == list(rouskin_shard.slice(0, 64).lengths)
+
+
+def test_full_rouskin_shard_config2(gpu_encoder, golden, rouskin_shard):
+    """BASELINE config 2: the whole 897,588-node shard, default limits → 15
+    micro-batches; every 97th row against the reference."""
+    g = golden("rouskin_full.npz")
+    outputs = gpu_encoder.encode_graphs(rouskin_shard)
+    assert len(outputs) == rouskin_shard.record_count
+    got = np.concatenate(outputs)
+    assert got.shape == (897_588, 128)
+    sampled = got[::int(g["stride"])]
+    diff = np.abs(sampled.astype(np.float64) - g["rows"].astype(np.float64))
+    assert diff.max() <= F16_TOL, diff.max()
+    norms = np.linalg.norm(got[::1009].astype(np.float64), axis=1)
+    np.testing.assert_allclose(norms, 1.0, atol=1e-3)
+
+
+def test_microbatch_layout_does_not_change_results(gpu_encoder, rouskin_shard):
+    part = rouskin_shard.slice(0, 200)
+    whole = np.concatenate(gpu_encoder.encode_graphs(part))
+    small = np.concatenate(gpu_encoder.encode_graphs(
+        part, max_batch_nodes=4000, max_batch_edges=20000))
+    np.testing.assert_array_equal(whole, small)
+
+
+def test_synthetic_roofline_shard_config3(gpu_encoder, golden):
+    from ginfinity_amd import synthetic
+    g = golden("synthetic.npz")
+    for seed in (0, 1):
+        shard = synthetic.roofline_shard(seed)
+        got = np.concatenate(gpu_encoder.encode_graphs(shard))
+        assert _maxabs(got[g[f"seed{seed}.rows"]], g[f"seed{seed}.out.m16"]) <= F16_TOL
+
+
+def test_arbitrary_shard_with_context_rows(gpu_encoder, golden):
+    from ginfinity_amd import synthetic
+    g = golden("arbitrary.npz")
+    shard = synthetic.arbitrary_shard(0)
+    outputs = gpu_encoder.encode_graphs(shard)
+    assert [o.shape[0] for o in outputs] == list(shard.core_counts)
+    got = np.concatenate(outputs)[::int(g["stride"])]
+    assert _maxabs(got, g["out.m16"]) <= F16_TOL
+
+
+def test_degenerate_and_sliced_graphs(gpu_encoder, golden):
+    from ginfinity_amd import RNA
+    g = golden("degenerate.npz")
+    for seq, struct in (("A", "."), ("AC", ".."), ("GC", "()")):
+        out = gpu_encoder.encode(RNA(seq, seq, struct))
+        assert _maxabs(out, g[f"{seq}.out.m16"]) <= F16_TOL
+    s = golden("sliced.npz")
+    record = RNA("stem", "GGGAAACCCUUUUGGG", "......(((....)))", start=9, end=16)
+    for hops in (1, 2, 3):
+        out = gpu_encoder.encode(record, keep_paired_neighbours=True, context_hops=hops)
+        assert out.shape == (7, 128)
+        assert _maxabs(out, s[f"hops{hops}.out.m16"]) <= F16_TOL
+    assert _maxabs(gpu_encoder.encode(record), s["nokeep.out.m16"]) <= F16_TOL
+
+
+def test_random_weights_against_oracle(golden):
+    """Parity must not depend on the bundled weights: seeded random weights of
+    the same shapes, HIP vs oracle."""
+    import torch
+    from oracle import gine_numpy as G
+    from ginfinity_amd import synthetic
+    from ginfinity_amd.engine import DeviceEncoder
+    from ginfinity_amd.weights import (EncoderConfig, build_weight_pack,
+                                       load_checkpoint, random_state)
+    config = load_checkpoint().config
+    state = random_state(config, seed=7)
+    engine = DeviceEncoder(build_weight_pack(state, config), full_precision=False,
+                           device=torch.device("cuda"))
+    shard = synthetic.arbitrary_shard(3, nodes=3000, edges=14000)
+    out = engine.encode_arrays(shard.node_features, shard.edge_index,
+                               shard.edge_types, None).cpu().numpy()
+    want = G.encode(G.Weights.from_state_dict(state), shard.node_features,
+                    shard.edge_index, shard.edge_types)
+    assert _maxabs(out, want) <= F16_TOL
+    engine.close()
+
+
+# ---- API behaviour on the device ----------------------------------------------------------
+
+def test_api_contract(gpu_encoder):
+    from ginfinity_amd import (GraphBuilder, GraphCompatibilityError, GraphSpec, RNA)
+    first, second = RNA("first", "ACGU", "...."), RNA("second", "GGAA", "(())")
+    outputs = gpu_encoder.encode_many([first, second])
+    assert [o.shape for o in outputs] == [(4, 128), (4, 128)]
+    assert gpu_encoder.encode_many([]) == []
+    assert gpu_encoder.encode_graphs([]) == []
+    with pytest.raises(ValueError, match="duplicate"):
+        gpu_encoder.encode_many([first, first])
+    with pytest.raises(ValueError, match="floating-point"):
+        gpu_encoder.encode(first, embedding_dtype="int8")
+    graph = GraphBuilder().build(RNA("rna-1", "ACGUACGU", "((....))"))
+    with pytest.raises(ValueError, match="max_batch_edges"):
+        gpu_encoder.encode_graphs([graph], max_batch_edges=29)
+    other = GraphSpec(struct_feature="B", positional=True, edge_dim=10,
+                      extra_edges=("skip2",))
+    with pytest.raises(GraphCompatibilityError, match="incompatible"):
+        gpu_encoder.encode_graph(GraphBuilder(other).build(first))
+    assert gpu_encoder.info()["parameter_count"] == 306_436
+    assert gpu_encoder.embedding_dimension == 128
