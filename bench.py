@@ -1,0 +1,193 @@
+"""Headline benchmark: encoded nodes/s on synthetic 60,000-node / 300,000-edge
+shards (BASELINE.json configs[2]), fp16 model, inputs resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One step = one pass of the hot path over one shard: COO→CSR build, input
+Linear, 4 fused GINE layers, head + float64 L2 normalise, embeddings left on
+the device.  Multi-GPU: shards are independent, every rank encodes
+its own shards, there is no data-path collective ("weak" scaling); the only
+communication is the barrier and the MAX-reduction of the elapsed time.
+
+Rank 0 prints ONE JSON line.  Besides the contract keys it carries
+  roofline      dominant kernel (k_gine_layer_f16): algorithmic bytes per launch
+                (512·N + 9·E + layer weights) ÷ its mean
+                duration measured with HIP events on the launch stream
+  cpu_baseline  oracle/gine_torch.py (the reference's aten op sequence) timed on
+                this box's host cores on the same workload — N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+NODES, EDGES = 60_000, 300_000
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s HBM3E (spec)
+MFMA_PEAK_TFLOPS = 2500.0        # dense fp16
+POOL = 4                         # distinct shards per rank, cycled
+
+# algorithmic bytes, SURVEY §8(d):  whole shard  2,332·N + 36·E + 612,872
+PIPELINE_BYTES = 2332 * NODES + 36 * EDGES + 612_872
+# one GINE layer launch: h read + h write (fp16) + COO once + that layer's fp16 weights
+LAYER_WEIGHT_BYTES = 2 * (256 * 128 + 128 * 256 + 10 * 128 + 256 + 4 * 256 + 128 + 2 * 128)
+LAYER_BYTES = 512 * NODES + 9 * EDGES + LAYER_WEIGHT_BYTES
+LAYER_FLOPS = NODES * 2 * (128 * 256 + 256 * 128)
+
+
+def parse() -> argparse.Namespace:
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--gpus", type=int, default=1)
+    parser.add_argument("--steps", type=int, default=200)
+    parser.add_argument("--warmup", type=int, default=20)
+    parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--cpu-seconds", type=float, default=12.0)
+    return parser.parse_args()
+
+
+def cpu_baseline(seconds: float) -> dict:
+    """Reference-equivalent CPU encode (same aten ops) on the same workload."""
+    from ginfinity_amd import synthetic
+    from ginfinity_amd.weights import load_checkpoint
+    from oracle import gine_torch
+
+    params = gine_torch.prepare(load_checkpoint().state)
+    shard = synthetic.roofline_shard(0)
+    arrays = (shard.node_features, shard.edge_index, shard.edge_types)
+    gine_torch.encode(params, *arrays)                       # warm
+    done, began = 0, time.perf_counter()
+    while done < 3 or time.perf_counter() - began < seconds:
+        gine_torch.encode(params, *arrays)
+        done += 1
+    elapsed = time.perf_counter() - began
+    return {"value": done * NODES / elapsed, "unit": "nodes/s",
+            "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{done} encodes of the 60000-node/300000-edge synthetic "
+                      f"shard, fp16 model, {elapsed:.1f} s, oracle/gine_torch.py "
+                      f"(reference aten op sequence), host has {os.cpu_count()} cpus"}
+
+
+def main() -> None:
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    from ginfinity_amd import Ginfinity, synthetic
+    encoder = Ginfinity.load(f"cuda:{local_rank}")
+    engine = encoder._engine
+
+    # inputs resident in HBM before the timed region
+    shards = [synthetic.roofline_shard(1000 * rank + i) for i in range(POOL)]
+    assert all((s.node_count, s.edge_count) == (NODES, EDGES) for s in shards)
+    inputs = [(torch.from_numpy(s.node_features).to(device),
+               torch.from_numpy(s.edge_index).to(device),
+               torch.from_numpy(s.edge_types).to(device)) for s in shards]
+    outputs = [torch.empty((NODES, 128), dtype=torch.float16, device=device)
+               for _ in range(POOL)]
+
+    def step(i: int) -> None:
+        x, ei, et = inputs[i % POOL]
+        csr = engine.build_csr(ei, et, NODES)
+        engine.encode(x, csr, out=outputs[i % POOL])
+
+    def fence() -> None:
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    began = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - began
+    if distributed:
+        worst = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        elapsed = float(worst.item())
+    fence()
+
+    # ---- per-kernel device time (HIP events on the launch stream), rank 0 -------
+    roofline = None
+    kernels = None
+    if rank == 0:
+        engine.set_timing(True)
+        rounds = min(args.steps, 50)
+        sums = None
+        csr_ms = 0.0
+        for i in range(rounds):
+            x, ei, et = inputs[i % POOL]
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            csr = engine.build_csr(ei, et, NODES)
+            e1.record()
+            engine.encode(x, csr, out=outputs[i % POOL])
+            times = engine.kernel_times_ms()
+            csr_ms += e0.elapsed_time(e1)
+            sums = times if sums is None else [a + b for a, b in zip(sums, times)]
+        engine.set_timing(False)
+        mean = [t / rounds for t in sums]
+        layer_ms = sum(mean[1:-1]) / (len(mean) - 2)
+        achieved = LAYER_BYTES / (layer_ms * 1e-3) / 1e9
+        roofline = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "kernel": "k_gine_layer_f16", "kernel_ms": layer_ms,
+            "algorithmic_bytes_per_launch": LAYER_BYTES,
+            "mfma_tflops": LAYER_FLOPS / (layer_ms * 1e-3) / 1e12,
+            "mfma_frac": LAYER_FLOPS / (layer_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+            "pipeline_frac": PIPELINE_BYTES * world * args.steps / elapsed / 1e9
+                             / (HBM_PEAK_GBS * world),
+        }
+        kernels = {"csr_build_ms": csr_ms / rounds, "input_linear_ms": mean[0],
+                   "layer_ms": mean[1:-1], "head_normalise_ms": mean[-1]}
+
+    baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        baseline = cpu_baseline(args.cpu_seconds)
+
+    if rank == 0:
+        value = world * args.steps * NODES / elapsed
+        print(json.dumps({
+            "metric": "encoded nodes/sec on 60k-node/300k-edge shards",
+            "value": value, "unit": "nodes/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "synthetic shard max_batch_nodes=60000 / "
+                                   "max_batch_edges=300000 (BASELINE configs[2]), "
+                                   "fp16 model, fp16 normalised output",
+                       "nodes_per_step": NODES, "edges_per_step": EDGES,
+                       "shards_per_rank": POOL, "parallelism": f"shard-parallel x{world}"},
+            "roofline": roofline, "cpu_baseline": baseline, "kernels_ms": kernels,
+        }))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

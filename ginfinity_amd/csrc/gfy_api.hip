@@ -143,8 +143,8 @@ int gfy_encoder_create(const void* weight_pack_host, size_t bytes,
   // offsets first (pointers are fixed up after the single upload)
   struct LayerOff {
     size_t table, w0, b0, alpha, shift, w1, b1, lg, lb;               // f16 mode
-    size_t ew, eb, fw0, fb0, g, b, mean, var, fw1, fb1, flg, flb;     // f32 mode
-    float scale, eps;
+    size_t ftable, fw0, fb0, falpha, fshift, fw1, fb1, flg, flb;      // f32 mode
+    float scale, one_plus_eps;
   };
   size_t o_win = 0, o_bin = 0, o_wa = 0, o_ba = 0, o_wb = 0, o_bb = 0;
   std::vector<LayerOff> lo(L);
@@ -155,14 +155,18 @@ int gfy_encoder_create(const void* weight_pack_host, size_t bytes,
     o_win = blob.reserve((size_t)H * 8 * sizeof(f16));
     o_bin = blob.reserve(H * sizeof(f16));
     for (int c = 0; c < H; ++c) {
+      // packed [c & 7][c >> 3][k]: see k_input_linear_f16
       for (int k = 0; k < kInDim; ++k)
-        blob.at<f16>(o_win)[c * 8 + k] = rh(w_in[c * kInDim + k]);
+        blob.at<f16>(o_win)[((c & 7) * 16 + (c >> 3)) * 8 + k] =
+            rh(w_in[c * kInDim + k]);
       blob.at<f16>(o_bin)[c] = rh(b_in[c]);
     }
   } else {
     o_win = blob.reserve((size_t)H * kInDim * 4);
     o_bin = blob.reserve(H * 4);
-    std::memcpy(blob.at<float>(o_win), w_in, (size_t)H * kInDim * 4);
+    for (int c = 0; c < H; ++c)
+      for (int k = 0; k < kInDim; ++k)
+        blob.at<float>(o_win)[k * H + c] = w_in[c * kInDim + k];  // [K][N]
     std::memcpy(blob.at<float>(o_bin), b_in, H * 4);
   }
 
@@ -223,16 +227,30 @@ int gfy_encoder_create(const void* weight_pack_host, size_t bytes,
         std::memcpy(blob.at<float>(off), src, n * 4);
         return off;
       };
-      o.eps = eps[0];
-      o.ew = put(ew, (size_t)H * ED);
-      o.eb = put(eb, H);
-      o.fw0 = put(w0, (size_t)M * H);
+      auto put_transposed = [&](const float* src, int rows, int cols) {
+        const size_t off = blob.reserve((size_t)rows * cols * 4);
+        for (int r = 0; r < rows; ++r)
+          for (int c = 0; c < cols; ++c)
+            blob.at<float>(off)[(size_t)c * rows + r] = src[(size_t)r * cols + c];
+        return off;
+      };
+      o.one_plus_eps = 1.0f + eps[0];
+      o.ftable = blob.reserve((size_t)kMaxEdgeTypes * H * 4);
+      for (int t = 0; t < ED; ++t)
+        for (int c = 0; c < H; ++c)
+          blob.at<float>(o.ftable)[t * H + c] = ew[c * ED + t] + eb[c];
+      o.fw0 = put_transposed(w0, M, H);   // -> [H][M]
       o.fb0 = put(b0, M);
-      o.g = put(bg, M);
-      o.b = put(bb, M);
-      o.mean = put(bm, M);
-      o.var = put(bv, M);
-      o.fw1 = put(w1, (size_t)H * M);
+      o.falpha = blob.reserve(M * 4);
+      o.fshift = blob.reserve(M * 4);
+      for (int c = 0; c < M; ++c) {
+        const float invstd = 1.0f / std::sqrt(bv[c] + 1e-5f);
+        const float alpha = invstd * bg[c];
+        const float prod = bm[c] * alpha;
+        blob.at<float>(o.falpha)[c] = alpha;
+        blob.at<float>(o.fshift)[c] = bb[c] - prod;
+      }
+      o.fw1 = put_transposed(w1, H, M);   // -> [M][H]
       o.fb1 = put(b1, H);
       o.flg = put(lg, H);
       o.flb = put(lb, H);
@@ -258,11 +276,14 @@ int gfy_encoder_create(const void* weight_pack_host, size_t bytes,
     }
   } else {
     o_wa = blob.reserve((size_t)H * H * 4);
-    std::memcpy(blob.at<float>(o_wa), wa, (size_t)H * H * 4);
+    o_wb = blob.reserve((size_t)kOutDim * H * 4);
+    for (int r = 0; r < H; ++r)
+      for (int c = 0; c < H; ++c) {
+        blob.at<float>(o_wa)[(size_t)c * H + r] = wa[(size_t)r * H + c];
+        blob.at<float>(o_wb)[(size_t)c * kOutDim + r] = wb[(size_t)r * H + c];
+      }
     o_ba = blob.reserve(H * 4);
     std::memcpy(blob.at<float>(o_ba), ba, H * 4);
-    o_wb = blob.reserve((size_t)kOutDim * H * 4);
-    std::memcpy(blob.at<float>(o_wb), wb, (size_t)kOutDim * H * 4);
     o_bb = blob.reserve(kOutDim * 4);
     std::memcpy(blob.at<float>(o_bb), bbias, kOutDim * 4);
   }
@@ -301,36 +322,62 @@ int gfy_encoder_create(const void* weight_pack_host, size_t bytes,
     }
     enc->f16.head = HeadF16{H16(o_wa), H16(o_ba), H16(o_wb), H16(o_bb)};
   } else {
-    enc->f32.w_in = F32p(o_win);
+    enc->f32.w_in_t = F32p(o_win);
     enc->f32.b_in = F32p(o_bin);
     for (int l = 0; l < L; ++l) {
       LayerF32& d = enc->f32.layer[l];
       const LayerOff& o = lo[l];
-      d.edge_w = F32p(o.ew);
-      d.edge_b = F32p(o.eb);
-      d.eps = o.eps;
-      d.w0 = F32p(o.fw0);
+      d.table = F32p(o.ftable);
+      d.one_plus_eps = o.one_plus_eps;
+      d.w0t = F32p(o.fw0);
       d.b0 = F32p(o.fb0);
-      d.bn_g = F32p(o.g);
-      d.bn_b = F32p(o.b);
-      d.bn_mean = F32p(o.mean);
-      d.bn_var = F32p(o.var);
-      d.w1 = F32p(o.fw1);
+      d.alpha = F32p(o.falpha);
+      d.shift = F32p(o.fshift);
+      d.w1t = F32p(o.fw1);
       d.b1 = F32p(o.fb1);
       d.ln_g = F32p(o.flg);
       d.ln_b = F32p(o.flb);
     }
-    enc->f32.ha_w = F32p(o_wa);
+    enc->f32.ha_wt = F32p(o_wa);
     enc->f32.ha_b = F32p(o_ba);
-    enc->f32.hb_w = F32p(o_wb);
+    enc->f32.hb_wt = F32p(o_wb);
     enc->f32.hb_b = F32p(o_bb);
   }
   *out = enc;
   return GFY_OK;
 }
 
+int gfy_encoder_set_timing(gfy_encoder* enc, int enable) {
+  clear_error();
+  GFY_REQUIRE(enc != nullptr, GFY_ERR_INVALID, "gfy_encoder_set_timing: encoder is NULL");
+  if (enable && !enc->events[0]) {
+    GFY_CHECK_HIP(hipSetDevice(enc->device));
+    for (auto& ev : enc->events) GFY_CHECK_HIP(hipEventCreate(&ev));
+  }
+  enc->timing = enable != 0;
+  enc->events_recorded = 0;
+  return GFY_OK;
+}
+
+int gfy_encoder_get_timing(gfy_encoder* enc, float* ms_host, int capacity, int* count) {
+  clear_error();
+  GFY_REQUIRE(enc && ms_host && count, GFY_ERR_INVALID, "gfy_encoder_get_timing: NULL argument");
+  const int spans = enc->events_recorded - 1;
+  GFY_REQUIRE(enc->timing && spans >= 1, GFY_ERR_INVALID,
+              "gfy_encoder_get_timing: timing is off or nothing was recorded");
+  GFY_REQUIRE(capacity >= spans, GFY_ERR_INVALID,
+              "gfy_encoder_get_timing: capacity %d < %d", capacity, spans);
+  GFY_CHECK_HIP(hipEventSynchronize(enc->events[spans]));
+  for (int i = 0; i < spans; ++i)
+    GFY_CHECK_HIP(hipEventElapsedTime(&ms_host[i], enc->events[i], enc->events[i + 1]));
+  *count = spans;
+  return GFY_OK;
+}
+
 void gfy_encoder_destroy(gfy_encoder* enc) {
   if (!enc) return;
+  for (auto& ev : enc->events)
+    if (ev) (void)hipEventDestroy(ev);
   if (enc->device_blob) (void)hipFree(enc->device_blob);
   delete enc;
 }

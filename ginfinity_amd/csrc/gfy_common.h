@@ -72,30 +72,30 @@ struct HeadF16 {
 };
 
 struct ModelF16 {
-  const f16* w_in;  // [128][8] (k padded 7 -> 8 with zero)
+  const f16* w_in;  // [8][16][8]: [c & 7][c >> 3][k], k padded 7 -> 8 with zero
   const f16* b_in;  // [128]
   LayerF16 layer[kMaxLayers];
   HeadF16 head;
 };
 
-// ---- fp32 (full_precision) parameters: plain row-major fp32 on the device --------
+// ---- fp32 (full_precision) parameters, derived on the host in fp32 ----------------
 struct LayerF32 {
-  const float* edge_w;  // [128][edge_dim]
-  const float* edge_b;  // [128]
-  float eps;
-  const float* w0;  // [256][128]
-  const float* b0;
-  const float *bn_g, *bn_b, *bn_mean, *bn_var;
-  const float* w1;  // [128][256]
-  const float* b1;
+  const float* table;   // [kMaxEdgeTypes][128]  fl32(W_edge[:,t] + b_edge)
+  float one_plus_eps;   // fl32(1 + eps)
+  const float* w0t;     // [128][256]  mlp.0.weight transposed ([K][N])
+  const float* b0;      // [256]
+  const float* alpha;   // [256]  invstd * gamma
+  const float* shift;   // [256]  beta - mean * alpha
+  const float* w1t;     // [256][128]  mlp.4.weight transposed
+  const float* b1;      // [128]
   const float *ln_g, *ln_b;
 };
 
 struct ModelF32 {
-  const float* w_in;  // [128][7]
+  const float* w_in_t;  // [7][128]
   const float* b_in;
   LayerF32 layer[kMaxLayers];
-  const float *ha_w, *ha_b, *hb_w, *hb_b;
+  const float *ha_wt, *ha_b, *hb_wt, *hb_b;  // head, weights transposed
 };
 
 }  // namespace gfy
@@ -110,6 +110,16 @@ struct gfy_encoder {
   size_t device_blob_bytes = 0;
   gfy::ModelF16 f16{};
   gfy::ModelF32 f32{};
+  // optional per-kernel timing (gfy_encoder_set_timing)
+  bool timing = false;
+  hipEvent_t events[gfy::kMaxLayers + 3] = {};
+  mutable int events_recorded = 0;
+  void mark(hipStream_t s, int slot) const {
+    if (timing) {
+      (void)hipEventRecord(events[slot], s);
+      events_recorded = slot + 1;
+    }
+  }
 };
 
 // ---- kernel launchers (one per .hip file) -------------------------------------------

@@ -84,8 +84,12 @@ struct TileWalk {
 // input Linear: h0 = R(R(x) . Win^T + b)            (_model.py:67, api.py:237-238)
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_input_linear_f16(
-    const float* __restrict__ x, const f16* __restrict__ w_in /*[128][8]*/,
+    const float* __restrict__ x, const f16* __restrict__ w_in /*[8][16][8] packed*/,
     const f16* __restrict__ b_in, f16* __restrict__ h, int n) {
+  // 16 lanes per node, 8 channels per lane.  w_in is stored [c][chunk][k]
+  // (channel = 8*chunk + c) so that for a fixed c the 16 lanes of a node read
+  // 256 contiguous bytes: a per-channel-row layout makes every lane hit its
+  // own 128-B line and costs ~64 cycles per load instruction (measured).
   const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t node = item >> 4;
   const int chunk = (int)(item & 15);
@@ -93,15 +97,15 @@ __global__ __launch_bounds__(256) void k_input_linear_f16(
   float xv[kInDim];
 #pragma unroll
   for (int k = 0; k < kInDim; ++k) xv[k] = (float)(f16)x[node * kInDim + k];
+  const f16x8 bias = *reinterpret_cast<const f16x8*>(b_in + chunk * 8);
   f16x8 out;
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
-    const int ch = chunk * 8 + c;
-    const f16x8 w = *reinterpret_cast<const f16x8*>(w_in + ch * 8);
+    const f16x8 w = *reinterpret_cast<const f16x8*>(w_in + (c * 16 + chunk) * 8);
     float acc = 0.f;
 #pragma unroll
     for (int k = 0; k < kInDim; ++k) acc = __builtin_fmaf(xv[k], (float)w[k], acc);
-    out[c] = (f16)(acc + (float)b_in[ch]);
+    out[c] = (f16)(acc + (float)bias[c]);
   }
   *reinterpret_cast<f16x8*>(h + node * kHidden + chunk * 8) = out;
 }
@@ -498,8 +502,10 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
   const int grid = persistent_grid(num_tiles);
 
   const int64_t items = n * 16;
+  enc->mark(s, 0);
   k_input_linear_f16<<<(int)((items + 255) / 256), 256, 0, s>>>(
       x, enc->f16.w_in, enc->f16.b_in, ha, (int)n);
+  enc->mark(s, 1);
   const int stop = tap_stage >= 0 ? tap_stage : enc->layers;
   for (int l = 0; l < stop; ++l) {
     if (enc->residual)
@@ -511,6 +517,7 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
     f16* sw = ha;
     ha = hb;
     hb = sw;
+    enc->mark(s, 2 + l);
   }
   if (tap_stage >= 0) {
     const int64_t chunks = n * 16;
@@ -533,6 +540,7 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
       k_head_f16<double><<<grid, kThreads, head_lds, s>>>(
           enc->f16.head, ha, out_rows, (double*)out, (int)n, num_tiles, normalise);
   }
+  enc->mark(s, 2 + enc->layers);
   GFY_CHECK_HIP(hipGetLastError());
   return GFY_OK;
 }

@@ -1,11 +1,332 @@
-// full_precision (fp32) encode path — placeholder until the fp64-accumulate kernels land.
+// full_precision (fp32 model) GINE encode for gfx950.
+//
+// Reference: Ginfinity.load(full_precision=True) keeps fp32 parameters and
+// activations (src/ginfinity/api.py:110-112); operator order as in
+// src/ginfinity/_model.py:39-46,65-72.  The north-star tolerance for this mode
+// is 1e-6 against the reference's own fp32 CPU encode, only ~2x that run's own
+// distance from an exact evaluation (4.96e-7).  So nothing here
+// runs at reduced precision: every dot product is accumulated in fp64 on the
+// vector ALU and rounded ONCE to fp32 where the reference materialises an fp32
+// tensor; element-wise ops round exactly where torch's do.  This mode is a
+// parity feature, not a benchmark configuration (it is MFMA/VALU-bound:
+// SURVEY §8d) — the kernels are written for clarity and coalesced access, not
+// for the roofline.
+//
+//   k_input_f32         h0 = fl32(x . Win^T + b)
+//   k_gather_f32        z  = fl32(fl32((1+eps) h) + sum_e relu(fl32(h[src] + T[type])))
+//                       (sequential fp32 adds in COO order = CPU index_add_)
+//   k_dense_f32<EPI>    out = EPI(fl32(in . W^T + b)), W pre-transposed to [K][N]
+//                       EPI: BatchNorm+ReLU | LayerNorm+residual | ReLU |
+//                            float64 normalise + cast + core-row scatter
 #include "gfy_common.h"
+
 namespace gfy {
-size_t encode_f32_workspace_bytes(int64_t n, int64_t) { return 2 * align_up((size_t)n * kHidden * 4, 256); }
-int launch_encode_f32(const gfy_encoder*, const float*, const int32_t*, const int32_t*,
-                      const uint8_t*, int64_t, int64_t, const int32_t*, void*, int, int, int,
-                      void*, size_t, hipStream_t) {
-  set_error("gfy_encode: fp32 model path not built yet");
-  return GFY_ERR_UNSUPPORTED;
+namespace {
+
+constexpr int kRowsPerBlock = 32;  // 4 waves x 8 rows
+constexpr int kRowsPerWave = 8;
+
+enum Epilogue { kEpiBnRelu = 0, kEpiLnResidual = 1, kEpiRelu = 2, kEpiOutput = 3 };
+
+struct DenseArgs {
+  const float* in;      // [n][K]
+  const float* wt;      // [K][NOUT]  (transposed on the host)
+  const float* bias;    // [NOUT]
+  float* out;           // [n][NOUT]  (not for kEpiOutput)
+  // BatchNorm (eval): alpha/shift precomputed per channel
+  const float* alpha;
+  const float* shift;
+  // LayerNorm + residual
+  const float* gamma;
+  const float* beta;
+  const float* residual;  // [n][NOUT] or nullptr
+  // final output
+  void* final_out;
+  const int32_t* out_rows;
+  int out_dtype;
+  int normalise;
+  int n;
+};
+
+__global__ __launch_bounds__(256) void k_input_f32(
+    const float* __restrict__ x, const float* __restrict__ wt /*[7][128]*/,
+    const float* __restrict__ b, float* __restrict__ h, int n) {
+  const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t node = item >> 7;
+  const int c = (int)(item & 127);
+  if (node >= n) return;
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < kInDim; ++k)
+    acc += (double)x[node * kInDim + k] * (double)wt[k * kHidden + c];
+  h[node * kHidden + c] = (float)(acc + (double)b[c]);
 }
+
+// one thread per (node, 4 channels)
+__global__ __launch_bounds__(256) void k_gather_f32(
+    const float* __restrict__ h, const float* __restrict__ table /*[16][128]*/,
+    float one_plus_eps, const int32_t* __restrict__ row_ptr,
+    const int32_t* __restrict__ col, const uint8_t* __restrict__ typ,
+    float* __restrict__ z, int n) {
+  const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t node = item >> 5;
+  const int c4 = (int)(item & 31);
+  if (node >= n) return;
+  const f32x4 hs = *reinterpret_cast<const f32x4*>(h + node * kHidden + c4 * 4);
+  f32x4 agg = {0.f, 0.f, 0.f, 0.f};
+  const int lo = row_ptr[node], hi = row_ptr[node + 1];
+  for (int e = lo; e < hi; ++e) {
+    const int s = col[e];
+    const int t = typ[e];
+    const f32x4 hv = *reinterpret_cast<const f32x4*>(h + (size_t)s * kHidden + c4 * 4);
+    const f32x4 tv = *reinterpret_cast<const f32x4*>(table + t * kHidden + c4 * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float m = hv[j] + tv[j];
+      agg[j] = agg[j] + (m > 0.f ? m : 0.f);
+    }
+  }
+  f32x4 out;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) out[j] = one_plus_eps * hs[j] + agg[j];  // contraction off: two roundings
+  *reinterpret_cast<f32x4*>(z + node * kHidden + c4 * 4) = out;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+__device__ __forceinline__ f16 f64_to_f16_once(double x) {
+  float f = (float)x;
+  const double back = (double)f;
+  if (back != x) {
+    uint32_t bits = __float_as_uint(f);
+    if (__builtin_fabs(back) > __builtin_fabs(x)) bits -= 1u;
+    bits |= 1u;
+    f = __uint_as_float(bits);
+  }
+  return (f16)f;
+}
+
+// Block: 4 waves; wave w owns rows [8w, 8w+8) of a 32-row tile; lane l owns
+// columns l, l+64, ... .  The activation tile sits in LDS (broadcast reads), the
+// transposed weight rows are read coalesced from L1/L2.
+template <int K, int NOUT, int EPI>
+__global__ __launch_bounds__(256) void k_dense_f32(const DenseArgs a) {
+  constexpr int kCols = NOUT / 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tile = reinterpret_cast<float*>(smem);  // [32][K]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int64_t base = (int64_t)blockIdx.x * kRowsPerBlock;
+
+  for (int i = t; i < kRowsPerBlock * K / 4; i += 256) {
+    const int row = (i * 4) / K;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (base + row < a.n)
+      v = reinterpret_cast<const f32x4*>(a.in + base * K)[i];
+    reinterpret_cast<f32x4*>(tile)[i] = v;
+  }
+  __syncthreads();
+
+  double acc[kRowsPerWave][kCols];
+#pragma unroll
+  for (int r = 0; r < kRowsPerWave; ++r)
+#pragma unroll
+    for (int j = 0; j < kCols; ++j) acc[r][j] = 0.0;
+  const float* xrow = tile + (wave * kRowsPerWave) * K;
+#pragma unroll 4
+  for (int k = 0; k < K; ++k) {
+    double w[kCols];
+#pragma unroll
+    for (int j = 0; j < kCols; ++j) w[j] = (double)a.wt[k * NOUT + lane + 64 * j];
+#pragma unroll
+    for (int r = 0; r < kRowsPerWave; ++r) {
+      const double xv = (double)xrow[r * K + k];
+#pragma unroll
+      for (int j = 0; j < kCols; ++j) acc[r][j] = __builtin_fma(xv, w[j], acc[r][j]);
+    }
+  }
+
+  float bias[kCols];
+#pragma unroll
+  for (int j = 0; j < kCols; ++j) bias[j] = a.bias[lane + 64 * j];
+
+#pragma unroll
+  for (int r = 0; r < kRowsPerWave; ++r) {
+    const int64_t node = base + wave * kRowsPerWave + r;
+    float y[kCols];
+#pragma unroll
+    for (int j = 0; j < kCols; ++j) y[j] = (float)(acc[r][j] + (double)bias[j]);  // the Linear's fp32 output
+
+    if constexpr (EPI == kEpiBnRelu) {
+#pragma unroll
+      for (int j = 0; j < kCols; ++j) {
+        const int c = lane + 64 * j;
+        const float v = __builtin_fmaf(y[j], a.alpha[c], a.shift[c]);
+        if (node < a.n) a.out[node * NOUT + c] = v > 0.f ? v : 0.f;
+      }
+    } else if constexpr (EPI == kEpiRelu) {
+#pragma unroll
+      for (int j = 0; j < kCols; ++j)
+        if (node < a.n) a.out[node * NOUT + lane + 64 * j] = y[j] > 0.f ? y[j] : 0.f;
+    } else if constexpr (EPI == kEpiLnResidual) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < kCols; ++j) s += (double)y[j];
+      const double mean64 = wave_sum(s) * (1.0 / NOUT);
+      double q = 0.0;
+#pragma unroll
+      for (int j = 0; j < kCols; ++j) {
+        const double d = (double)y[j] - mean64;
+        q += d * d;
+      }
+      const float var = (float)(wave_sum(q) * (1.0 / NOUT));
+      const float mean = (float)mean64;
+      const float rstd = 1.0f / __builtin_sqrtf(var + 1e-5f);
+      const float offset = -rstd * mean;
+#pragma unroll
+      for (int j = 0; j < kCols; ++j) {
+        const int c = lane + 64 * j;
+        const float u = __builtin_fmaf(__builtin_fmaf(y[j], rstd, offset), a.gamma[c], a.beta[c]);
+        if (node < a.n)
+          a.out[node * NOUT + c] = a.residual ? a.residual[node * NOUT + c] + u : u;
+      }
+    } else {  // kEpiOutput: float64 normalise, one rounding to the output dtype
+      double v[kCols];
+      double ss = 0.0;
+#pragma unroll
+      for (int j = 0; j < kCols; ++j) {
+        v[j] = (double)y[j];
+        ss += v[j] * v[j];
+      }
+      ss = wave_sum(ss);
+      if (a.normalise) {
+        const double nrm = __builtin_sqrt(ss);
+        const double den = nrm > 1e-12 ? nrm : 1e-12;
+#pragma unroll
+        for (int j = 0; j < kCols; ++j) v[j] = v[j] / den;
+      }
+      if (node < a.n) {
+        const int64_t dest = a.out_rows ? a.out_rows[node] : node;
+        if (dest >= 0) {
+#pragma unroll
+          for (int j = 0; j < kCols; ++j) {
+            const int64_t at = dest * NOUT + lane + 64 * j;
+            if (a.out_dtype == GFY_F16)
+              reinterpret_cast<f16*>(a.final_out)[at] = f64_to_f16_once(v[j]);
+            else if (a.out_dtype == GFY_F32)
+              reinterpret_cast<float*>(a.final_out)[at] = (float)v[j];
+            else
+              reinterpret_cast<double*>(a.final_out)[at] = v[j];
+          }
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_copy_f32(const float* __restrict__ src,
+                                                  float* __restrict__ dst, int64_t count4) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < count4; i += stride)
+    reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(src)[i];
+}
+
+template <int K, int NOUT, int EPI>
+void launch_dense(const DenseArgs& a, hipStream_t s) {
+  const int blocks = (a.n + kRowsPerBlock - 1) / kRowsPerBlock;
+  k_dense_f32<K, NOUT, EPI><<<blocks, 256, kRowsPerBlock * K * sizeof(float), s>>>(a);
+}
+
+}  // namespace
+
+// workspace: h (128), z (128), v (256), h2 (128) floats per node
+size_t encode_f32_workspace_bytes(int64_t n, int64_t /*e*/) {
+  return align_up((size_t)n * (3 * kHidden + kMlp) * sizeof(float), 256);
+}
+
+int launch_encode_f32(const gfy_encoder* enc, const float* x,
+                      const int32_t* row_ptr, const int32_t* col,
+                      const uint8_t* typ, int64_t n, int64_t e,
+                      const int32_t* out_rows, void* out, int out_dtype,
+                      int normalise, int tap_stage, void* ws, size_t ws_bytes,
+                      hipStream_t s) {
+  const size_t need = encode_f32_workspace_bytes(n, e);
+  GFY_REQUIRE(ws_bytes >= need, GFY_ERR_WORKSPACE,
+              "gfy_encode: workspace %zu < required %zu", ws_bytes, need);
+  float* h = (float*)ws;
+  float* z = h + (size_t)n * kHidden;
+  float* v = z + (size_t)n * kHidden;
+  float* h2 = v + (size_t)n * kMlp;
+  const ModelF32& m = enc->f32;
+  const int nn = (int)n;
+
+  enc->mark(s, 0);
+  {
+    const int64_t items = n * kHidden;
+    k_input_f32<<<(int)((items + 255) / 256), 256, 0, s>>>(x, m.w_in_t, m.b_in, h, nn);
+  }
+  enc->mark(s, 1);
+  const int stop = tap_stage >= 0 ? tap_stage : enc->layers;
+  for (int l = 0; l < stop; ++l) {
+    const LayerF32& p = m.layer[l];
+    const int64_t items = n * 32;
+    k_gather_f32<<<(int)((items + 255) / 256), 256, 0, s>>>(
+        h, p.table, p.one_plus_eps, row_ptr, col, typ, z, nn);
+    DenseArgs a{};
+    a.n = nn;
+    a.in = z;
+    a.wt = p.w0t;
+    a.bias = p.b0;
+    a.out = v;
+    a.alpha = p.alpha;
+    a.shift = p.shift;
+    launch_dense<kHidden, kMlp, kEpiBnRelu>(a, s);
+    DenseArgs b{};
+    b.n = nn;
+    b.in = v;
+    b.wt = p.w1t;
+    b.bias = p.b1;
+    b.out = h2;
+    b.gamma = p.ln_g;
+    b.beta = p.ln_b;
+    b.residual = enc->residual ? h : nullptr;
+    launch_dense<kMlp, kHidden, kEpiLnResidual>(b, s);
+    float* sw = h;
+    h = h2;
+    h2 = sw;
+    enc->mark(s, 2 + l);
+  }
+  if (tap_stage >= 0) {
+    const int64_t count4 = n * kHidden / 4;
+    int g = (int)((count4 + 255) / 256);
+    k_copy_f32<<<g > 2048 ? 2048 : g, 256, 0, s>>>(h, (float*)out, count4);
+    GFY_CHECK_HIP(hipGetLastError());
+    return GFY_OK;
+  }
+  DenseArgs a{};
+  a.n = nn;
+  a.in = h;
+  a.wt = m.ha_wt;
+  a.bias = m.ha_b;
+  a.out = z;
+  launch_dense<kHidden, kHidden, kEpiRelu>(a, s);
+  DenseArgs b{};
+  b.n = nn;
+  b.in = z;
+  b.wt = m.hb_wt;
+  b.bias = m.hb_b;
+  b.final_out = out;
+  b.out_rows = out_rows;
+  b.out_dtype = out_dtype;
+  b.normalise = normalise;
+  launch_dense<kHidden, kOutDim, kEpiOutput>(b, s);
+  enc->mark(s, 2 + enc->layers);
+  GFY_CHECK_HIP(hipGetLastError());
+  return GFY_OK;
+}
+
 }  // namespace gfy

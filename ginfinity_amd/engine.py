@@ -158,6 +158,21 @@ class DeviceEncoder:
                 "gfy_encode_hidden")
         return out
 
+    # -- diagnostics -------------------------------------------------------------------
+    def set_timing(self, enabled: bool) -> None:
+        native.check(self._lib.gfy_encoder_set_timing(
+            self._handle, 1 if enabled else 0), "gfy_encoder_set_timing")
+
+    def kernel_times_ms(self) -> list[float]:
+        """Device time of each kernel of the last ``encode`` (timing enabled):
+        [input Linear, layer 0.., head+normalise]."""
+        buffer = (ctypes.c_float * 16)()
+        count = ctypes.c_int()
+        native.check(self._lib.gfy_encoder_get_timing(
+            self._handle, buffer, 16, ctypes.byref(count)),
+            "gfy_encoder_get_timing")
+        return [float(buffer[i]) for i in range(count.value)]
+
     # -- one micro-batch, host arrays in → device embeddings out ----------------------
     def encode_arrays(self, node_features: np.ndarray, edge_index: np.ndarray,
                       edge_types: np.ndarray, node_roles: np.ndarray | None,

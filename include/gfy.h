@@ -126,6 +126,16 @@ int gfy_encode_hidden(gfy_encoder* encoder, const float* node_features,
                       int stage, void* out, void* workspace,
                       size_t workspace_bytes, void* stream);
 
+/* Per-kernel device timing of gfy_encode (diagnostics; bench.py's roofline
+ * figure).  While enabled, gfy_encode brackets each kernel with hipEvents on the
+ * caller's stream (do not enable under graph capture).  gfy_encoder_get_timing
+ * waits for the last gfy_encode and writes milliseconds to ms_host:
+ * [0] input Linear, [1..layers] GINE layers, [layers+1] head+normalise;
+ * *count receives layers+2. */
+int gfy_encoder_set_timing(gfy_encoder* encoder, int enable);
+int gfy_encoder_get_timing(gfy_encoder* encoder, float* ms_host, int capacity,
+                           int* count);
+
 /* ---- all-pairs distance over 128-d embeddings ----------------------------------
  * No reference symbol (the aligner lives in the external `ginfinity-sw`;
  * only parameters are exported: api.py:47-50, data/alignment.json:6) — defined

@@ -237,3 +237,66 @@ def test_api_contract(gpu_encoder):
         gpu_encoder.encode_graph(GraphBuilder(other).build(first))
     assert gpu_encoder.info()["parameter_count"] == 306_436
     assert gpu_encoder.embedding_dimension == 128
+
+
+# ---- full_precision (fp32 model) ------------------------------------------------------------
+
+def test_fp32_model_example8(gpu_encoder_fp32, golden):
+    from ginfinity_amd import RNA
+    g = golden("example8.npz")
+    record = RNA("example", "ACGUACGU", "((....))")
+    assert gpu_encoder_fp32.full_precision
+    for dtype, tol in (("float32", F32_TOL), ("float64", F32_TOL), ("float16", 5e-4)):
+        got = gpu_encoder_fp32.encode(record, embedding_dtype=dtype)
+        assert got.dtype == np.dtype(dtype)
+        assert _maxabs(got, g[f"out.m32.{dtype}"]) <= tol, dtype
+    assert gpu_encoder_fp32.encode(record).dtype == np.float16      # default output dtype
+
+
+def test_fp32_model_rouskin16(gpu_encoder_fp32, golden, rouskin_shard):
+    g = golden("rouskin64.npz")
+    got = np.concatenate(gpu_encoder_fp32.encode_graphs(
+        rouskin_shard.slice(0, 16), embedding_dtype=np.float32))
+    assert got.shape == g["out.m32.float32"].shape
+    worst = _maxabs(got, g["out.m32.float32"])
+    print(f"fp32 model, 2356 nodes: max|hip - reference| = {worst:.3e}")
+    assert worst <= F32_TOL
+
+
+def test_fp32_model_synthetic_arbitrary_sliced(gpu_encoder_fp32, golden):
+    from ginfinity_amd import RNA, synthetic
+    g = golden("synthetic.npz")
+    got = np.concatenate(gpu_encoder_fp32.encode_graphs(
+        synthetic.roofline_shard(0), embedding_dtype=np.float32))
+    worst = _maxabs(got[g["seed0.rows"]], g["seed0.out.m32.float32"])
+    print(f"fp32 model, synthetic rows: {worst:.3e}")
+    assert worst <= F32_TOL
+    a = golden("arbitrary.npz")
+    got = np.concatenate(gpu_encoder_fp32.encode_graphs(
+        synthetic.arbitrary_shard(0), embedding_dtype=np.float32))[::int(a["stride"])]
+    worst = _maxabs(got, a["out.m32.float32"])
+    print(f"fp32 model, arbitrary shard: {worst:.3e}")
+    assert worst <= F32_TOL
+    s = golden("sliced.npz")
+    record = RNA("stem", "GGGAAACCCUUUUGGG", "......(((....)))", start=9, end=16)
+    for hops in (1, 2, 3):
+        out = gpu_encoder_fp32.encode(record, keep_paired_neighbours=True,
+                                      context_hops=hops, embedding_dtype=np.float32)
+        assert _maxabs(out, s[f"hops{hops}.out.m32.float32"]) <= F32_TOL
+    d = golden("degenerate.npz")
+    for seq, struct in (("A", "."), ("AC", ".."), ("GC", "()")):
+        out = gpu_encoder_fp32.encode(RNA(seq, seq, struct), embedding_dtype=np.float32)
+        assert _maxabs(out, d[f"{seq}.out.m32.float32"]) <= F32_TOL
+
+
+def test_fp32_hidden_against_float64_truth(gpu_encoder_fp32, oracle_weights, rouskin_shard):
+    from oracle import gine_numpy as G
+    shard = rouskin_shard.slice(0, 16)
+    x, ei, et = _device_inputs(gpu_encoder_fp32, shard)
+    engine = gpu_encoder_fp32._engine
+    csr = engine.build_csr(ei, et, shard.node_count)
+    raw = engine.encode(x, csr, normalise=False, out_dtype=__import__("torch").float32).cpu().numpy()
+    truth = G.forward_f32(oracle_weights, shard.node_features, shard.edge_index,
+                          shard.edge_types, dtype=np.float64)
+    scale = np.abs(truth).max()
+    assert _maxabs(raw, truth) <= 2e-6 * scale

@@ -184,3 +184,22 @@ def test_distance_oracle_definitions():
             assert d[i, j] == pytest.approx(np.linalg.norm(a[i] - b[j]), rel=1e-12)
             assert s[i, j] == pytest.approx(
                 a[i] @ b[j] / np.linalg.norm(a[i]) / np.linalg.norm(b[j]), rel=1e-12)
+
+
+def test_torch_port_matches_reference_goldens(golden, checkpoint, rouskin_shard):
+    """oracle/gine_torch.py issues the reference's own aten op sequence: on the
+    machine that recorded the goldens it is bit-identical; elsewhere (other CPU
+    kernels) it must still be inside the fp16 tolerance."""
+    from oracle import gine_torch as T
+    g = golden("rouskin64.npz")
+    part = rouskin_shard.slice(0, 64)
+    params = T.prepare(checkpoint.state)
+    out = T.encode(params, part.node_features, part.edge_index, part.edge_types)
+    assert np.abs(out.astype(np.float64) - g["out.m16"].astype(np.float64)).max() <= F16_TOL
+    assert np.mean(out == g["out.m16"]) > 0.9
+    params32 = T.prepare(checkpoint.state, full_precision=True)
+    part16 = rouskin_shard.slice(0, 16)
+    out32 = T.encode(params32, part16.node_features, part16.edge_index,
+                     part16.edge_types, embedding_dtype=np.float32)
+    assert np.abs(out32.astype(np.float64)
+                  - g["out.m32.float32"].astype(np.float64)).max() <= F32_TOL

@@ -1,0 +1,104 @@
+// Stand-alone C++ driver of the C ABI (no Python, no torch): random weights,
+// a synthetic 60k-node / 300k-edge shard, per-kernel device times.
+//   hipcc -O2 tools/gfy_bench.cpp -Iinclude -Lginfinity_amd/csrc -lgfy -o tools/gfy_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+#include "gfy.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+#define GK(x) do { int s_ = (x); if (s_ != 0) { printf("gfy error %d: %s (line %d)\n", s_, gfy_last_error(), __LINE__); exit(1);} } while (0)
+
+int main(int argc, char** argv) {
+  const int64_t N = argc > 1 ? atoll(argv[1]) : 60000;
+  const int steps = argc > 2 ? atoi(argv[2]) : 200;
+  const int L = 4000;
+  std::mt19937 rng(1);
+  std::normal_distribution<float> nd(0.f, 1.f);
+  // weight pack
+  size_t bytes = gfy_weight_pack_bytes(7, 128, 4, 10, 128);
+  std::vector<char> pack(bytes);
+  uint32_t hd[8] = {0x31594647u, 1, 7, 128, 4, 10, 128, 1};
+  memcpy(pack.data(), hd, 32);
+  float* w = (float*)(pack.data() + 32);
+  size_t nf = (bytes - 32) / 4;
+  for (size_t i = 0; i < nf; ++i) w[i] = 0.08f * nd(rng);
+  // make running_var positive: simplest is abs()+0.5 everywhere it matters; use layout offsets
+  {
+    size_t off = 128 * 7 + 128;
+    for (int l = 0; l < 4; ++l) {
+      off += 1 + 128 * 10 + 128 + 256 * 128 + 256;  // eps, edge_lin, mlp0
+      off += 256 * 3;                                // bn w,b,mean
+      for (int c = 0; c < 256; ++c) w[off + c] = 0.5f + fabsf(w[off + c]) * 4.f;
+      off += 256;
+      off += 128 * 256 + 128 + 256;                  // mlp4, ln
+    }
+  }
+  gfy_encoder* enc = nullptr;
+  GK(gfy_encoder_create(pack.data(), bytes, GFY_F16, 0, &enc));
+  // graph: records of L nodes: backbone both ways, skip2 both ways, random matching both ways
+  const int64_t recs = N / L;
+  std::vector<int32_t> src, dst; std::vector<uint8_t> typ;
+  for (int64_t r = 0; r < recs; ++r) {
+    int32_t b = (int32_t)(r * L);
+    for (int i = 0; i + 1 < L; ++i) { src.push_back(b + i); dst.push_back(b + i + 1); typ.push_back(0); }
+    for (int i = 0; i + 1 < L; ++i) { src.push_back(b + i + 1); dst.push_back(b + i); typ.push_back(1); }
+    std::vector<int32_t> perm(L); for (int i = 0; i < L; ++i) perm[i] = i;
+    std::shuffle(perm.begin(), perm.end(), rng);
+    for (int i = 0; i < L; i += 2) { src.push_back(b + perm[i]); dst.push_back(b + perm[i + 1]); typ.push_back(2); }
+    for (int i = 0; i < L; i += 2) { src.push_back(b + perm[i + 1]); dst.push_back(b + perm[i]); typ.push_back(3); }
+    for (int i = 0; i + 2 < L; ++i) { src.push_back(b + i); dst.push_back(b + i + 2); typ.push_back(4);
+                                      src.push_back(b + i + 2); dst.push_back(b + i); typ.push_back(5); }
+    for (int i = 0; i < 6; ++i) { src.push_back(b + rng() % L); dst.push_back(b + rng() % L); typ.push_back(2); }
+  }
+  const int64_t E = (int64_t)src.size();
+  std::vector<int32_t> ei(2 * E);
+  memcpy(ei.data(), src.data(), E * 4); memcpy(ei.data() + E, dst.data(), E * 4);
+  std::vector<float> x(N * 7);
+  for (auto& v : x) v = nd(rng);
+  float* dx; int32_t *dei, *drp, *dcol; uint8_t *det, *dtyp; void *dout, *ws1, *ws2;
+  CK(hipMalloc(&dx, N * 7 * 4)); CK(hipMalloc(&dei, 2 * E * 4)); CK(hipMalloc(&det, E));
+  CK(hipMalloc(&drp, (N + 1) * 4)); CK(hipMalloc(&dcol, E * 4)); CK(hipMalloc(&dtyp, E));
+  CK(hipMalloc(&dout, N * 128 * 2));
+  size_t b1 = gfy_csr_workspace_bytes(N, E), b2 = gfy_encode_workspace_bytes(enc, N, E);
+  CK(hipMalloc(&ws1, b1)); CK(hipMalloc(&ws2, b2));
+  CK(hipMemcpy(dx, x.data(), N * 7 * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dei, ei.data(), 2 * E * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(det, typ.data(), E, hipMemcpyHostToDevice));
+  hipStream_t s; CK(hipStreamCreate(&s));
+  hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
+  for (int i = 0; i < 20; ++i) {
+    GK(gfy_build_csr(dei, det, N, E, drp, dcol, dtyp, ws1, b1, s));
+    GK(gfy_encode(enc, dx, drp, dcol, dtyp, N, E, nullptr, dout, GFY_F16, 1, ws2, b2, s));
+  }
+  CK(hipStreamSynchronize(s));
+  CK(hipEventRecord(e0, s));
+  for (int i = 0; i < steps; ++i) {
+    GK(gfy_build_csr(dei, det, N, E, drp, dcol, dtyp, ws1, b1, s));
+    GK(gfy_encode(enc, dx, drp, dcol, dtyp, N, E, nullptr, dout, GFY_F16, 1, ws2, b2, s));
+  }
+  CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  printf("N=%lld E=%lld  csr+encode: %.1f us/step  -> %.1f M nodes/s\n", (long long)N, (long long)E, 1e3 * ms / steps, N * steps / ms / 1e3);
+  CK(hipEventRecord(e0, s));
+  for (int i = 0; i < steps; ++i)
+    GK(gfy_encode(enc, dx, drp, dcol, dtyp, N, E, nullptr, dout, GFY_F16, 1, ws2, b2, s));
+  CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  printf("encode only: %.1f us/step\n", 1e3 * ms / steps);
+  GK(gfy_encoder_set_timing(enc, 1));
+  double sum[16] = {0}; int cnt = 0;
+  for (int i = 0; i < 50; ++i) {
+    GK(gfy_encode(enc, dx, drp, dcol, dtyp, N, E, nullptr, dout, GFY_F16, 1, ws2, b2, s));
+    float t[16]; GK(gfy_encoder_get_timing(enc, t, 16, &cnt));
+    for (int k = 0; k < cnt; ++k) sum[k] += t[k];
+  }
+  printf("per-kernel us:");
+  for (int k = 0; k < cnt; ++k) printf(" %.1f", 1e3 * sum[k] / 50);
+  printf("\n");
+  gfy_encoder_destroy(enc);
+  return 0;
+}
