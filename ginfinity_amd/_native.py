@@ -40,7 +40,7 @@ SIGNATURES: dict[str, tuple] = {
     "gfy_encoder_get_timing": (c_int, [c_void_p, c_void_p, c_int,
                                        POINTER(c_int)]),
     "gfy_pairwise_dense": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int,
-                                   c_void_p, c_void_p]),
+                                   c_void_p, c_void_p, c_size_t, c_void_p]),
     "gfy_pairwise_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "gfy_pairwise_nearest": (c_int, [c_void_p, c_int64, c_void_p, c_int64,
                                      c_int, c_int64, c_void_p, c_void_p,

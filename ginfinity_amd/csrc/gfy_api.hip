@@ -447,13 +447,14 @@ int gfy_encode_hidden(gfy_encoder* enc, const float* x, const int32_t* row_ptr,
 }
 
 int gfy_pairwise_dense(const void* a, int64_t n, const void* b, int64_t m,
-                       int metric, float* out, void* stream) {
+                       int metric, float* out, void* ws, size_t ws_bytes,
+                       void* stream) {
   clear_error();
-  GFY_REQUIRE(a && b && out && n > 0 && m > 0, GFY_ERR_INVALID,
+  GFY_REQUIRE(a && b && out && ws && n > 0 && m > 0, GFY_ERR_INVALID,
               "gfy_pairwise_dense: bad arguments");
   GFY_REQUIRE(metric == GFY_L2 || metric == GFY_COSINE, GFY_ERR_INVALID,
               "gfy_pairwise_dense: unknown metric %d", metric);
-  return launch_pairwise_dense(a, n, b, m, metric, out, (hipStream_t)stream);
+  return launch_pairwise_dense(a, n, b, m, metric, out, ws, ws_bytes, (hipStream_t)stream);
 }
 
 size_t gfy_pairwise_workspace_bytes(int64_t n, int64_t m) {

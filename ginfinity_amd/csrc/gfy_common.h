@@ -147,7 +147,8 @@ int launch_encode_f32(const gfy_encoder* enc, const float* x,
 size_t encode_f32_workspace_bytes(int64_t n, int64_t e);
 
 int launch_pairwise_dense(const void* a, int64_t n, const void* b, int64_t m,
-                          int metric, float* out, hipStream_t s);
+                          int metric, float* out, void* ws, size_t ws_bytes,
+                          hipStream_t s);
 int launch_pairwise_nearest(const void* a, int64_t n, const void* b, int64_t m,
                             int metric, int64_t exclude_offset, float* best_val,
                             int32_t* best_idx, void* ws, size_t ws_bytes,

@@ -1,14 +1,367 @@
-// all-pairs distance — placeholder until the MFMA kernel lands.
+// All-pairs L2 / cosine over 128-d fp16 embeddings on the gfx950 matrix cores.
+//
+// The reference ships no implementation of this half of the north star (the
+// aligner is the external `ginfinity-sw`; src/ginfinity/api.py:47-50 only
+// exports its parameters), so the definition is ours:
+//   L2      D_ij = sqrt(max(|a_i|^2 + |b_j|^2 - 2 a_i.b_j, 0))
+//   cosine  S_ij = a_i.b_j / (max(|a_i|,1e-12) max(|b_j|,1e-12))
+// oracle: oracle/gine_numpy.py pairwise_l2 / pairwise_cosine (float64).
+//
+// One kernel serves both outputs.  A workgroup (4 waves, 2x2) owns 128 a-rows,
+// whose MFMA fragments stay in registers, and sweeps its chunk of b-rows in
+// 128-row tiles staged through LDS (coalesced 256-B rows, XOR-swizzled chunks).
+// The product is taken as (B-tile) x (A-block)^T so the a-row sits on the MFMA
+// lane: the running best of an a-row is lane-local state and a lane's four
+// consecutive accumulator registers are four consecutive b-rows.
+// Both metrics reduce to minimising  key_ij = fma(dot_ij, s_j, t_j):
+//   L2      (s_j, t_j) = (-2, |b_j|^2)          value = sqrt(max(|a_i|^2 + key, 0))
+//   cosine  (s_j, t_j) = (-1/|b_j|, 0)          value = -key / |a_i|
+// `nearest` keeps (min key, arg min) per a-row, ties to the lowest index; with
+// the b-rows split over several workgroups the partial results are merged by a
+// second small kernel.  Workgroups are numbered chunk-major so the ones running
+// together sweep the same b-tiles and share them through L2.
 #include "gfy_common.h"
+
 namespace gfy {
-size_t pairwise_workspace_bytes(int64_t, int64_t) { return 256; }
-int launch_pairwise_dense(const void*, int64_t, const void*, int64_t, int, float*, hipStream_t) {
-  set_error("gfy_pairwise_dense: not built yet");
-  return GFY_ERR_UNSUPPORTED;
+namespace {
+
+constexpr int kBlockA = 128;  // a-rows per workgroup
+constexpr int kTileB = 128;   // b-rows per LDS tile
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ int off256(int row, int chunk) {
+  return row * 256 + ((chunk ^ (row & 15)) << 4);
 }
-int launch_pairwise_nearest(const void*, int64_t, const void*, int64_t, int, int64_t, float*,
-                            int32_t*, void*, size_t, hipStream_t) {
-  set_error("gfy_pairwise_nearest: not built yet");
-  return GFY_ERR_UNSUPPORTED;
+
+// per-row (s, t) on the b side, (na or 1/|a|) on the a side
+__global__ __launch_bounds__(256) void k_row_terms(const f16* __restrict__ rows, int64_t count,
+                                                   int metric, float* __restrict__ s_out,
+                                                   float* __restrict__ t_out,
+                                                   float* __restrict__ a_term) {
+  const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row = item >> 4;
+  const int chunk = (int)(item & 15);
+  float ss = 0.f;
+  if (row < count) {
+    const f16x8 v = *reinterpret_cast<const f16x8*>(rows + row * 128 + chunk * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ss = __builtin_fmaf((float)v[j], (float)v[j], ss);
+  }
+#pragma unroll
+  for (int m = 1; m < 16; m <<= 1) ss += __shfl_xor(ss, m, 64);
+  if (row < count && chunk == 0) {
+    const float nrm = __builtin_sqrtf(ss);
+    const float inv = 1.0f / (nrm > 1e-12f ? nrm : 1e-12f);
+    if (s_out) {
+      s_out[row] = metric == GFY_L2 ? -2.0f : -inv;
+      t_out[row] = metric == GFY_L2 ? ss : 0.0f;
+    }
+    if (a_term) a_term[row] = metric == GFY_L2 ? ss : inv;
+  }
 }
+
+struct PairArgs {
+  const f16* a;
+  const f16* b;
+  const float* s;       // [m]
+  const float* t;       // [m]
+  const float* a_term;  // [n]
+  int64_t n, m;
+  int metric;
+  int64_t exclude_offset;
+  int blocks_a, chunks;
+  int64_t chunk_rows;   // multiple of kTileB
+  float* part_val;      // [chunks][n]   (nearest)
+  int32_t* part_idx;    // [chunks][n]
+  float* dense;         // [n][m]        (dense)
+};
+
+template <bool kDense>
+__global__ __launch_bounds__(kThreads, 2) void k_pairwise(const PairArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* tile = smem;                                            // 128 x 256 B
+  float* s_l = reinterpret_cast<float*>(smem + kTileB * 256);   // [128]
+  float* t_l = s_l + kTileB;                                     // [128]
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int r = lane & 31, hq = lane >> 5;
+  const int wa = wave & 1, wb = wave >> 1;  // wave owns a-rows [64wa,64wa+64), b-rows [64wb, 64wb+64) of each tile
+  const int chunk = blockIdx.x / p.blocks_a;
+  const int block_a = blockIdx.x - chunk * p.blocks_a;
+  const int64_t a0 = (int64_t)block_a * kBlockA;
+  const int64_t j_begin = (int64_t)chunk * p.chunk_rows;
+  const int64_t j_end = j_begin + p.chunk_rows < p.m ? j_begin + p.chunk_rows : p.m;
+
+  // stage the a-block through LDS once (coalesced), then keep fragments in registers
+  for (int i = t; i < kBlockA * 16; i += kThreads) {
+    const int row = i >> 4, ch = i & 15;
+    f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (a0 + row < p.n) v = *reinterpret_cast<const f16x8*>(p.a + (a0 + row) * 128 + ch * 8);
+    *reinterpret_cast<f16x8*>(tile + off256(row, ch)) = v;
+  }
+  __syncthreads();
+  f16x8 af[2][8];
+#pragma unroll
+  for (int at = 0; at < 2; ++at)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      af[at][ks] = *reinterpret_cast<const f16x8*>(tile + off256(64 * wa + 32 * at + r, 2 * ks + hq));
+  __syncthreads();
+
+  float best[2];
+  int bidx[2];
+#pragma unroll
+  for (int at = 0; at < 2; ++at) {
+    best[at] = __builtin_inff();
+    bidx[at] = 0x7fffffff;
+  }
+
+  for (int64_t j0 = j_begin; j0 < j_end; j0 += kTileB) {
+    for (int i = t; i < kTileB * 16; i += kThreads) {
+      const int row = i >> 4, ch = i & 15;
+      f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (j0 + row < p.m) v = *reinterpret_cast<const f16x8*>(p.b + (j0 + row) * 128 + ch * 8);
+      *reinterpret_cast<f16x8*>(tile + off256(row, ch)) = v;
+    }
+    if (t < kTileB) {
+      const bool ok = j0 + t < p.m;
+      s_l[t] = ok ? p.s[j0 + t] : 0.f;
+      t_l[t] = ok ? p.t[j0 + t] : __builtin_inff();   // key = +inf: never wins
+    }
+    __syncthreads();
+
+    f32x16 acc[2][2];  // [b-tile][a-tile]
+#pragma unroll
+    for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+      for (int at = 0; at < 2; ++at)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[bt][at][q] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+      for (int bt = 0; bt < 2; ++bt) {
+        const f16x8 bf = *reinterpret_cast<const f16x8*>(
+            tile + off256(64 * wb + 32 * bt + r, 2 * ks + hq));
+#pragma unroll
+        for (int at = 0; at < 2; ++at)
+          acc[bt][at] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf, af[at][ks], acc[bt][at], 0, 0, 0);
+      }
+    }
+
+    // does this tile contain an excluded (i, i + offset) pair of this block?
+    const int64_t ex_lo = a0 + p.exclude_offset, ex_hi = ex_lo + kBlockA;
+    const bool may_exclude = p.exclude_offset >= 0 && ex_lo < j0 + kTileB && ex_hi > j0;
+
+#pragma unroll
+    for (int bt = 0; bt < 2; ++bt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int jl = 64 * wb + 32 * bt + 8 * g + 4 * hq;  // 4 consecutive b-rows
+        const f32x4 sv = *reinterpret_cast<const f32x4*>(s_l + jl);
+        const f32x4 tv = *reinterpret_cast<const f32x4*>(t_l + jl);
+#pragma unroll
+        for (int at = 0; at < 2; ++at) {
+          const int64_t ai = a0 + 64 * wa + 32 * at + r;
+          if constexpr (kDense) {
+            const float aterm = ai < p.n ? p.a_term[ai] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int64_t j = j0 + jl + i;
+              const float key = __builtin_fmaf(acc[bt][at][4 * g + i], sv[i], tv[i]);
+              if (ai < p.n && j < p.m) {
+                float val;
+                if (p.metric == GFY_L2) {
+                  const float d2 = aterm + key;
+                  val = __builtin_sqrtf(d2 > 0.f ? d2 : 0.f);
+                } else {
+                  val = -key * aterm;
+                }
+                p.dense[ai * p.m + j] = val;
+              }
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float key = __builtin_fmaf(acc[bt][at][4 * g + i], sv[i], tv[i]);
+              const int j = (int)(j0 + jl + i);
+              if (may_exclude && (int64_t)j == ai + p.exclude_offset) key = __builtin_inff();
+              if (key < best[at]) {   // ascending j inside a lane: strict < keeps the lowest index
+                best[at] = key;
+                bidx[at] = j;
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if constexpr (!kDense) {
+    // merge the two lane halves (different b-rows, same a-row), then the two
+    // waves that share this a-row range (wb = 0/1) through LDS
+    float* m_val = reinterpret_cast<float*>(smem);          // [2 wb][128]
+    int* m_idx = reinterpret_cast<int*>(smem + 2 * kBlockA * 4);
+#pragma unroll
+    for (int at = 0; at < 2; ++at) {
+      const float ov = __shfl_xor(best[at], 32, 64);
+      const int oi = __shfl_xor(bidx[at], 32, 64);
+      if (ov < best[at] || (ov == best[at] && oi < bidx[at])) {
+        best[at] = ov;
+        bidx[at] = oi;
+      }
+      if (hq == 0) {
+        m_val[wb * kBlockA + 64 * wa + 32 * at + r] = best[at];
+        m_idx[wb * kBlockA + 64 * wa + 32 * at + r] = bidx[at];
+      }
+    }
+    __syncthreads();
+    if (t < kBlockA && a0 + t < p.n) {
+      float v0 = m_val[t], v1 = m_val[kBlockA + t];
+      int i0 = m_idx[t], i1 = m_idx[kBlockA + t];
+      if (v1 < v0 || (v1 == v0 && i1 < i0)) {
+        v0 = v1;
+        i0 = i1;
+      }
+      p.part_val[(int64_t)chunk * p.n + a0 + t] = v0;
+      p.part_idx[(int64_t)chunk * p.n + a0 + t] = i0;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_nearest_finish(const float* __restrict__ part_val,
+                                                        const int32_t* __restrict__ part_idx,
+                                                        const float* __restrict__ a_term,
+                                                        int64_t n, int chunks, int metric,
+                                                        float* __restrict__ best_val,
+                                                        int32_t* __restrict__ best_idx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = part_val[i];
+  int idx = part_idx[i];
+  for (int c = 1; c < chunks; ++c) {
+    const float ov = part_val[(int64_t)c * n + i];
+    const int oi = part_idx[(int64_t)c * n + i];
+    if (ov < v || (ov == v && oi < idx)) {
+      v = ov;
+      idx = oi;
+    }
+  }
+  const float at = a_term[i];
+  float out;
+  if (metric == GFY_L2) {
+    const float d2 = at + v;
+    out = __builtin_sqrtf(d2 > 0.f ? d2 : 0.f);
+  } else {
+    out = -v * at;
+  }
+  best_val[i] = out;
+  best_idx[i] = idx == 0x7fffffff ? -1 : idx;
+}
+
+struct PairWorkspace {
+  float *s, *t, *a_term, *part_val;
+  int32_t* part_idx;
+  int blocks_a, chunks;
+  int64_t chunk_rows;
+  size_t bytes;
+};
+
+PairWorkspace carve(void* base, int64_t n, int64_t m) {
+  PairWorkspace w;
+  w.blocks_a = (int)((n + kBlockA - 1) / kBlockA);
+  const int64_t tiles_b = (m + kTileB - 1) / kTileB;
+  int64_t chunks = (1024 + w.blocks_a - 1) / w.blocks_a;
+  if (chunks > tiles_b) chunks = tiles_b;
+  if (chunks < 1) chunks = 1;
+  const int64_t tiles_per_chunk = (tiles_b + chunks - 1) / chunks;
+  w.chunk_rows = tiles_per_chunk * kTileB;
+  w.chunks = (int)((tiles_b + tiles_per_chunk - 1) / tiles_per_chunk);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    void* ptr = base ? (char*)base + off : nullptr;
+    off += align_up(bytes, 256);
+    return ptr;
+  };
+  w.s = (float*)take((size_t)m * 4);
+  w.t = (float*)take((size_t)m * 4);
+  w.a_term = (float*)take((size_t)n * 4);
+  w.part_val = (float*)take((size_t)w.chunks * n * 4);
+  w.part_idx = (int32_t*)take((size_t)w.chunks * n * 4);
+  w.bytes = off;
+  return w;
+}
+
+constexpr int kPairLds = kTileB * 256 + 2 * kTileB * 4;
+
+}  // namespace
+
+size_t pairwise_workspace_bytes(int64_t n, int64_t m) { return carve(nullptr, n, m).bytes; }
+
+int launch_pairwise_nearest(const void* a, int64_t n, const void* b, int64_t m,
+                            int metric, int64_t exclude_offset, float* best_val,
+                            int32_t* best_idx, void* ws, size_t ws_bytes,
+                            hipStream_t s) {
+  const PairWorkspace w = carve(ws, n, m);
+  GFY_REQUIRE(ws_bytes >= w.bytes, GFY_ERR_WORKSPACE,
+              "gfy_pairwise_nearest: workspace %zu < required %zu", ws_bytes, w.bytes);
+  const f16* ap = (const f16*)a;
+  const f16* bp = (const f16*)b;
+  k_row_terms<<<(int)((m * 16 + 255) / 256), 256, 0, s>>>(bp, m, metric, w.s, w.t, nullptr);
+  k_row_terms<<<(int)((n * 16 + 255) / 256), 256, 0, s>>>(ap, n, metric, nullptr, nullptr, w.a_term);
+  PairArgs p{};
+  p.a = ap;
+  p.b = bp;
+  p.s = w.s;
+  p.t = w.t;
+  p.a_term = w.a_term;
+  p.n = n;
+  p.m = m;
+  p.metric = metric;
+  p.exclude_offset = exclude_offset;
+  p.blocks_a = w.blocks_a;
+  p.chunks = w.chunks;
+  p.chunk_rows = w.chunk_rows;
+  p.part_val = w.part_val;
+  p.part_idx = w.part_idx;
+  k_pairwise<false><<<w.blocks_a * w.chunks, kThreads, kPairLds, s>>>(p);
+  k_nearest_finish<<<(int)((n + 255) / 256), 256, 0, s>>>(
+      w.part_val, w.part_idx, w.a_term, n, w.chunks, metric, best_val, best_idx);
+  GFY_CHECK_HIP(hipGetLastError());
+  return GFY_OK;
+}
+
+int launch_pairwise_dense(const void* a, int64_t n, const void* b, int64_t m,
+                          int metric, float* out, void* ws, size_t ws_bytes,
+                          hipStream_t s) {
+  const PairWorkspace w = carve(ws, n, m);
+  GFY_REQUIRE(ws_bytes >= w.bytes, GFY_ERR_WORKSPACE,
+              "gfy_pairwise_dense: workspace %zu < required %zu", ws_bytes, w.bytes);
+  float* sv = w.s;
+  float* tv = w.t;
+  float* at = w.a_term;
+  const f16* ap = (const f16*)a;
+  const f16* bp = (const f16*)b;
+  k_row_terms<<<(int)((m * 16 + 255) / 256), 256, 0, s>>>(bp, m, metric, sv, tv, nullptr);
+  k_row_terms<<<(int)((n * 16 + 255) / 256), 256, 0, s>>>(ap, n, metric, nullptr, nullptr, at);
+  PairArgs p{};
+  p.a = ap;
+  p.b = bp;
+  p.s = sv;
+  p.t = tv;
+  p.a_term = at;
+  p.n = n;
+  p.m = m;
+  p.metric = metric;
+  p.exclude_offset = -1;
+  p.blocks_a = (int)((n + kBlockA - 1) / kBlockA);
+  p.chunks = 1;
+  p.chunk_rows = (m + kTileB - 1) / kTileB * kTileB;
+  p.dense = out;
+  k_pairwise<true><<<p.blocks_a, kThreads, kPairLds, s>>>(p);
+  GFY_CHECK_HIP(hipGetLastError());
+  return GFY_OK;
+}
+
 }  // namespace gfy

@@ -144,16 +144,18 @@ int gfy_encoder_get_timing(gfy_encoder* encoder, float* ms_host, int capacity,
  * on the matrix cores.
  *   a [n][128] fp16, b [m][128] fp16.                                           */
 
+size_t gfy_pairwise_workspace_bytes(int64_t n, int64_t m);
+
 /* Dense block: out float32 [n][m]  (small blocks only: n*m*4 bytes). */
 int gfy_pairwise_dense(const void* a, int64_t n, const void* b, int64_t m,
-                       int metric, float* out, void* stream);
+                       int metric, float* out, void* workspace,
+                       size_t workspace_bytes, void* stream);
 
 /* Fused row reduction, the N x M matrix is never materialised:
  *   best_val float32 [n], best_idx int32 [n]: nearest b-row of each a-row
  *   (smallest distance for GFY_L2, largest similarity for GFY_COSINE; ties ->
  *   lowest index).  exclude_offset >= 0 skips the pair (i, i + exclude_offset)
  *   — "self" when b is a with a row offset; -1 excludes nothing.               */
-size_t gfy_pairwise_workspace_bytes(int64_t n, int64_t m);
 int gfy_pairwise_nearest(const void* a, int64_t n, const void* b, int64_t m,
                          int metric, int64_t exclude_offset, float* best_val,
                          int32_t* best_idx, void* workspace,

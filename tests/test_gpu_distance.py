@@ -1,0 +1,99 @@
+"""All-pairs distance against the float64 oracle definition.
+Parity is unpinned against the reference — it has no implementation — so the
+oracle is the mathematical definition (oracle/gine_numpy.py)."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rows(seed, count, unit=True):
+    rng = np.random.default_rng(seed)
+    data = rng.standard_normal((count, 128))
+    if unit:
+        data /= np.linalg.norm(data, axis=1, keepdims=True)
+    else:
+        data *= rng.uniform(0.2, 3.0, size=(count, 1))
+    return data.astype(np.float16)
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (130, 257), (300, 500)])
+@pytest.mark.parametrize("unit", [True, False])
+def test_dense_block_matches_oracle(n, m, unit):
+    from oracle import gine_numpy as G
+    from ginfinity_amd import distance
+    a, b = _rows(1, n, unit), _rows(2, m, unit)
+    d = distance.pairwise(a, b, metric="l2").cpu().numpy().astype(np.float64)
+    want = G.pairwise_l2(a, b)
+    scale = ((a.astype(np.float64) ** 2).sum(1)[:, None]
+             + (b.astype(np.float64) ** 2).sum(1)[None, :])
+    # tolerance is stated on d² (cancellation for near-duplicates)
+    assert np.abs(d ** 2 - want ** 2).max() <= 4e-6 * scale.max()
+    s = distance.pairwise(a, b, metric="cosine").cpu().numpy().astype(np.float64)
+    assert np.abs(s - G.pairwise_cosine(a, b)).max() <= 2e-6
+
+
+def test_dense_self_distance_is_small():
+    from ginfinity_amd import distance
+    a = _rows(3, 200)
+    d = distance.pairwise(a, metric="l2").cpu().numpy()
+    assert np.abs(np.diag(d)).max() <= 2e-3          # sqrt of ~1e-7 cancellation noise
+    s = distance.pairwise(a, metric="cosine").cpu().numpy()
+    np.testing.assert_allclose(np.diag(s), 1.0, atol=2e-6)
+
+
+@pytest.mark.parametrize("n,m", [(1000, 3000), (64, 20000), (129, 127)])
+@pytest.mark.parametrize("metric", ["l2", "cosine"])
+def test_nearest_matches_oracle(n, m, metric):
+    from oracle import gine_numpy as G
+    from ginfinity_amd import distance
+    a, b = _rows(4, n), _rows(5, m)
+    values, indices = distance.nearest(a, b, metric=metric)
+    values, indices = values.cpu().numpy().astype(np.float64), indices.cpu().numpy()
+    full = G.pairwise_l2(a, b) if metric == "l2" else G.pairwise_cosine(a, b)
+    best = full.min(axis=1) if metric == "l2" else full.max(axis=1)
+    picked = full[np.arange(n), indices]
+    assert indices.min() >= 0 and indices.max() < m
+    np.testing.assert_allclose(picked, best, atol=2e-6 if metric == "cosine" else 2e-5)
+    np.testing.assert_allclose(values, picked, atol=2e-6 if metric == "cosine" else 2e-5)
+
+
+def test_nearest_excludes_self_and_offset():
+    from oracle import gine_numpy as G
+    from ginfinity_amd import distance
+    rows = _rows(6, 700)
+    values, indices = distance.nearest(rows, metric="cosine", exclude_self=True)
+    indices = indices.cpu().numpy()
+    assert not np.any(indices == np.arange(700))
+    full = G.pairwise_cosine(rows, rows)
+    np.fill_diagonal(full, -np.inf)
+    np.testing.assert_allclose(values.cpu().numpy(), full.max(axis=1), atol=2e-6)
+    # a = rows[200:328] as a block of b = rows: skip (i, i + 200)
+    block = rows[200:328]
+    _, idx = distance.nearest(block, rows, metric="l2", exclude_offset=200)
+    idx = idx.cpu().numpy()
+    assert not np.any(idx == np.arange(128) + 200)
+    _, idx_plain = distance.nearest(block, rows, metric="l2")
+    np.testing.assert_array_equal(idx_plain.cpu().numpy(), np.arange(128) + 200)
+
+
+def test_nearest_ties_go_to_lowest_index():
+    from ginfinity_amd import distance
+    base = _rows(7, 300)
+    b = np.concatenate([base, base[:50], base])          # every row appears 2-3 times
+    _, idx = distance.nearest(base, b, metric="cosine")
+    np.testing.assert_array_equal(idx.cpu().numpy(), np.arange(300))
+
+
+def test_distance_on_real_embeddings(gpu_encoder, rouskin_shard):
+    from oracle import gine_numpy as G
+    from ginfinity_amd import distance
+    block, counts = gpu_encoder.encode_graphs_device(rouskin_shard.slice(0, 40))
+    assert block.shape[0] == sum(counts)
+    host = block.cpu().numpy()
+    sample = host[:512]
+    d = distance.pairwise(block[:512], block, metric="l2").cpu().numpy()
+    np.testing.assert_allclose(d.astype(np.float64) ** 2,
+                               G.pairwise_l2(sample, host) ** 2, atol=1e-5)
