@@ -97,3 +97,19 @@ def test_distance_on_real_embeddings(gpu_encoder, rouskin_shard):
     d = distance.pairwise(block[:512], block, metric="l2").cpu().numpy()
     np.testing.assert_allclose(d.astype(np.float64) ** 2,
                                G.pairwise_l2(sample, host) ** 2, atol=1e-5)
+
+
+def test_cross_shard_nearest_world_size_one(gpu_encoder):
+    """The multi-GPU search with one rank equals the single-GPU search with
+    self-pairs excluded (SURVEY §8e testability)."""
+    from ginfinity_amd import distance, parallel, synthetic
+    shards = [synthetic.arbitrary_shard(s, nodes=1500, edges=6000, records=3)
+              for s in (1, 2)]
+    block, owned, counts = parallel.encode_owned_shards(gpu_encoder, shards)
+    assert owned == [0, 1] and len(counts) == 2
+    assert block.shape[0] == sum(sum(c) for c in counts)
+    values, indices, offsets = parallel.cross_shard_nearest(block, metric="cosine")
+    assert offsets == [0, block.shape[0]]
+    ref_values, ref_indices = distance.nearest(block, metric="cosine", exclude_self=True)
+    np.testing.assert_array_equal(indices.cpu().numpy(), ref_indices.cpu().numpy())
+    np.testing.assert_array_equal(values.cpu().numpy(), ref_values.cpu().numpy())

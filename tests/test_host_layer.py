@@ -1,0 +1,287 @@
+"""Host-side drop-in surface: records, tables, graph builder, shard I/O,
+checkpoint loader, CLI (host-only commands).  Mirrors the reference's own test
+strategy (tests/test_validation.py, test_table.py, test_graph.py,
+test_sliced_graphs.py, test_api.py, test_encoder_cli.py) — CPU only."""
+from __future__ import annotations
+
+import hashlib
+import json
+import shutil
+
+import numpy as np
+import pytest
+from safetensors import safe_open
+from safetensors.numpy import save_file
+
+import ginfinity_amd.shard_io as shard_io
+from ginfinity_amd import (GRAPH_SHARD_FORMAT, GRAPH_SHARD_FORMAT_VERSION,
+                           NODE_ROLE_CONTEXT, NODE_ROLE_CORE, Ginfinity,
+                           GraphBuilder, GraphCompatibilityError, GraphShard,
+                           GraphSpec, GraphValidationError,
+                           InputValidationError, ModelIntegrityError, RNA,
+                           default_alignment_parameters, load_graph_shard,
+                           partition_records, read_rna_table, save_graph_shard)
+from ginfinity_amd.api import microbatch_bounds
+from ginfinity_amd.cli import main
+from ginfinity_amd.weights import load_checkpoint
+
+SEQ, STRUCT = "GGGAAACCCUUUUGGG", "......(((....)))"
+
+
+def _records():
+    return [RNA("rna-1", "ACGUACGU", "((....))"), RNA("rna-2", "GGAACCUU", "........")]
+
+
+# ---- records ------------------------------------------------------------------------
+
+def test_record_normalisation_and_rejection():
+    record = RNA(" id ", " acgt ", " (()) ")
+    assert (record.identifier, record.sequence, record.structure) == ("id", "ACGU", "(())")
+    for seq, struct, message in [("", "", "empty sequence"), ("ACGN", "....", "unsupported sequence"),
+                                 ("ACGU", "...", "characters against"),
+                                 ("ACGU", "[..]", "unsupported structure"),
+                                 ("ACGU", "((.)", "unmatched"), ("ACGU", ".)..", "unmatched")]:
+        with pytest.raises(InputValidationError, match=message):
+            RNA("id", seq, struct)
+    with pytest.raises(InputValidationError, match="identifier"):
+        RNA("bad\tid", "ACGU", "....")
+    with pytest.raises(InputValidationError, match="exceeds maximum"):
+        RNA("long", "A" * 4097, "." * 4097)
+    for start, end, message in [(1, None, "both be provided"), (-1, 2, "invalid slice"),
+                                (2, 2, "invalid slice"), (0, 5, "invalid slice")]:
+        with pytest.raises(InputValidationError, match=message):
+            RNA("id", "ACGU", "....", start=start, end=end)
+    window = RNA("id", "ACGUACGU", "((....))", start=2, end=6)
+    assert window.sliced and window.core_length == 4
+
+
+def test_mapping_and_table_reader(tmp_path):
+    record = RNA.from_mapping({"name": "r", "bases": "ACGT", "fold": "(())"},
+                              identifier_column="name", sequence_column="bases",
+                              structure_column="fold")
+    assert record == RNA("r", "ACGU", "(())")
+    with pytest.raises(InputValidationError, match="multiple slices"):
+        RNA.from_mapping({"transcript_id": "r", "sequence": "ACGUACGU",
+                          "secondary_structure": "((....))", "start": "2,4", "end": "6,8"},
+                         start_column="start", end_column="end")
+    table = tmp_path / "t.tsv"
+    table.write_text("transcript_id\tsequence\tsecondary_structure\tstart\tend\n"
+                     "rna-1\tACGUACGU\t((....))\t2,4\t6, 8\n")
+    got = read_rna_table(table)
+    assert [(r.identifier, r.start, r.end) for r in got] == [("rna-1:2-6", 2, 6), ("rna-1:4-8", 4, 8)]
+    table.write_text("transcript_id\tsequence\tsecondary_structure\tstart\tend\n"
+                     "rna-1\tACGUACGU\t((....))\t2,4\t6\n")
+    with pytest.raises(InputValidationError, match="start has 2"):
+        read_rna_table(table)
+    table.write_text("name\tbases\nfirst\tACGU\n")
+    with pytest.raises(ValueError, match="dot_bracket"):
+        read_rna_table(table, identifier_column="name", sequence_column="bases",
+                       structure_column="dot_bracket")
+    table.write_text("transcript_id\tsequence\tsecondary_structure\nbad\tACGN\t....\n")
+    with pytest.raises(InputValidationError, match="line 2"):
+        read_rna_table(table)
+    table.write_text("transcript_id\tsequence\tsecondary_structure\na\tACGU\t....\na\tACGU\t....\n")
+    with pytest.raises(InputValidationError, match="duplicate"):
+        read_rna_table(table)
+
+
+# ---- graph builder: integer known answers ----------------------------------------------
+
+def test_example8_arrays_are_the_reference_arrays(golden):
+    g = golden("example8.npz")
+    shard = GraphBuilder().build_shard([RNA("example", "ACGUACGU", "((....))")])
+    for name in ("node_features", "edge_index", "edge_types", "node_ptr", "edge_ptr",
+                 "residue_index", "node_roles"):
+        got, want = getattr(shard, name), g[name]
+        assert got.dtype == want.dtype and got.shape == want.shape, name
+        np.testing.assert_array_equal(got, want, err_msg=name)
+    # SURVEY §8-B known answers
+    np.testing.assert_array_equal(shard.edge_index[0, :7], np.arange(7))
+    np.testing.assert_array_equal(shard.edge_types[14:18], [2, 2, 3, 3])
+    np.testing.assert_array_equal(shard.edge_index[:, 18:22], [[0, 2, 1, 3], [2, 0, 3, 1]])
+    assert shard.spec.sha256 == "da2e670e377e47667fec8a8ebb1c90c6e506b9cdd8a5555a6bfab50b202fb9bd"
+
+
+def test_whole_rouskin_shard_hashes_match_reference_builder(golden, rouskin_shard):
+    want = golden("integers.json")["rouskin"]
+    assert (rouskin_shard.record_count, rouskin_shard.node_count,
+            rouskin_shard.edge_count) == (want["records"], want["nodes"], want["edges"])
+    for name, digest in want["sha256"].items():
+        got = hashlib.sha256(np.ascontiguousarray(getattr(rouskin_shard, name)).tobytes())
+        assert got.hexdigest() == digest, name
+    bounds = microbatch_bounds(rouskin_shard.lengths, rouskin_shard.edge_counts,
+                               60_000, 300_000)
+    assert [list(b) for b in bounds] == [w[:2] for w in want["microbatches_60000_300000"]]
+    piece = rouskin_shard.slice(413, 798)
+    assert (piece.node_count, piece.edge_count) == tuple(want["microbatches_60000_300000"][1][2:])
+    assert int(piece.edge_index.min()) >= 0 and int(piece.edge_index.max()) < piece.node_count
+    piece.validate_values()
+
+
+def test_sliced_graphs_match_reference(golden):
+    g = golden("sliced.npz")
+    for hops in (1, 2, 3):
+        graph = GraphBuilder(keep_paired_neighbours=True, context_hops=hops).build(
+            RNA("stem", SEQ, STRUCT, start=9, end=16))
+        for name in ("node_features", "edge_index", "edge_types", "residue_index", "node_roles"):
+            np.testing.assert_array_equal(getattr(graph, name), g[f"hops{hops}.{name}"])
+    plain = GraphBuilder().build(RNA("stem", SEQ, STRUCT, start=9, end=16))
+    np.testing.assert_array_equal(plain.residue_index, np.arange(9, 16, dtype=np.int32))
+    assert plain.core_span == (9, 16) and plain.core_count == 7
+    hops2 = GraphBuilder(keep_paired_neighbours=True, context_hops=2).build(
+        RNA("stem", SEQ, STRUCT, start=9, end=16))
+    np.testing.assert_array_equal(hops2.residue_index[hops2.node_roles == NODE_ROLE_CONTEXT],
+                                  [4, 5, 6, 7, 8])
+    with pytest.raises(ValueError, match="context_hops"):
+        GraphBuilder(context_hops=0)
+
+
+def test_degenerate_graphs(golden):
+    g = golden("degenerate.npz")
+    for seq, struct in (("A", "."), ("AC", ".."), ("GC", "()")):
+        graph = GraphBuilder().build(RNA(seq, seq, struct))
+        np.testing.assert_array_equal(graph.edge_index, g[f"{seq}.edge_index"])
+        np.testing.assert_array_equal(graph.edge_types, g[f"{seq}.edge_types"])
+        np.testing.assert_array_equal(graph.node_features, g[f"{seq}.node_features"])
+        assert graph.edge_index.shape == g[f"{seq}.edge_index"].shape
+
+
+def test_shard_validation_errors():
+    shard = GraphBuilder().build_shard(_records())
+    with pytest.raises(ValueError, match="duplicate"):
+        GraphBuilder().build_shard([_records()[0], _records()[0]])
+    with pytest.raises(GraphValidationError, match="edge type"):
+        GraphShard(**{**{f: getattr(shard, f) for f in shard.__slots__},
+                      "edge_types": np.full_like(shard.edge_types, 10)})
+    with pytest.raises(GraphValidationError, match="edge index"):
+        GraphShard(**{**{f: getattr(shard, f) for f in shard.__slots__},
+                      "edge_index": shard.edge_index + np.int32(100)})
+    with pytest.raises(IndexError):
+        shard.slice(1, 1)
+    other = GraphSpec(struct_feature="B", positional=True, edge_dim=10, extra_edges=("skip2",))
+    assert GraphBuilder(other).build(_records()[0]).node_features.shape == (8, 9)
+    with pytest.raises(GraphCompatibilityError):
+        GraphShard.from_graphs([GraphBuilder().build(_records()[0]),
+                                GraphBuilder(other).build(_records()[1])])
+    parts = list(partition_records([RNA(str(i), "ACGU", "....") for i in range(5)],
+                                   max_records=3, max_nodes=8))
+    assert [[r.identifier for r in p] for p in parts] == [["0", "1"], ["2", "3"], ["4"]]
+
+
+# ---- shard persistence --------------------------------------------------------------------
+
+def test_shard_round_trip_and_checksums(tmp_path, monkeypatch):
+    original = GraphBuilder().build_shard(_records())
+    path = tmp_path / "graphs.safetensors"
+    _, meta = save_graph_shard(original, path)
+    assert "tensor_sha256" not in json.loads(meta.read_text())
+    with safe_open(str(path), framework="np") as handle:
+        assert set(handle.keys()) == {"node_features", "edge_index", "edge_types",
+                                      "node_ptr", "edge_ptr"}
+    restored = load_graph_shard(path, validation="full")
+    assert restored.identifiers == original.identifiers and restored.spec == original.spec
+    for name in ("node_features", "edge_index", "edge_types", "node_ptr", "edge_ptr",
+                 "residue_index", "node_roles"):
+        np.testing.assert_array_equal(getattr(restored, name), getattr(original, name))
+    # hashing stays opt-in
+    monkeypatch.setattr(shard_io, "_sha256",
+                        lambda _p: (_ for _ in ()).throw(AssertionError("hashing must be opt-in")))
+    save_graph_shard(original, tmp_path / "again.safetensors")
+    assert load_graph_shard(tmp_path / "again.safetensors").record_count == 2
+    monkeypatch.undo()
+    save_graph_shard(original, path, checksum=True)
+    payload = bytearray(path.read_bytes())
+    payload[-1] ^= 1
+    path.write_bytes(payload)
+    with pytest.raises(GraphValidationError, match="checksum"):
+        load_graph_shard(path, verify_checksum=True)
+    incompatible = GraphSpec(struct_feature="B", positional=True, edge_dim=10,
+                             extra_edges=("skip2",))
+    save_graph_shard(original, path)
+    with pytest.raises(GraphCompatibilityError):
+        load_graph_shard(path, expected_spec=incompatible)
+
+
+def test_sliced_and_legacy_shards(tmp_path):
+    sliced = GraphBuilder(keep_paired_neighbours=True, context_hops=2).build_shard(
+        [RNA("stem", SEQ, STRUCT, start=9, end=16)])
+    path = tmp_path / "sliced.safetensors"
+    save_graph_shard(sliced, path)
+    with safe_open(str(path), framework="np") as handle:
+        assert {"residue_index", "node_roles"} <= set(handle.keys())
+    restored = load_graph_shard(path, validation="full")
+    np.testing.assert_array_equal(restored.node_roles, sliced.node_roles)
+    assert restored.core_counts == (7,) and restored.lengths[0] > 7
+    full = GraphBuilder().build_shard([RNA("stem", SEQ, STRUCT)])
+    legacy = tmp_path / "legacy.safetensors"
+    save_file({name: getattr(full, name) for name in
+               ("node_features", "edge_index", "edge_types", "node_ptr", "edge_ptr")},
+              str(legacy), metadata={"format": GRAPH_SHARD_FORMAT,
+                                     "format_version": str(GRAPH_SHARD_FORMAT_VERSION),
+                                     "graph_spec_sha256": full.spec.sha256})
+    (tmp_path / "legacy.json").write_text(json.dumps({
+        "format": GRAPH_SHARD_FORMAT, "format_version": GRAPH_SHARD_FORMAT_VERSION,
+        "graph_spec": full.spec.to_dict(), "graph_spec_sha256": full.spec.sha256,
+        "tensor_file": legacy.name, "record_count": 1, "node_count": 16,
+        "edge_count": full.edge_count, "identifiers": ["stem"], "sequences": [SEQ],
+        "structures": [STRUCT]}))
+    loaded = load_graph_shard(legacy)
+    np.testing.assert_array_equal(loaded.residue_index, full.residue_index)
+    assert np.all(loaded.node_roles == NODE_ROLE_CORE)
+
+
+# ---- loader / API behaviour that needs no GPU -------------------------------------------------
+
+def test_checkpoint_loader_and_integrity(tmp_path, checkpoint):
+    assert checkpoint.metadata["parameter_count"] == 306_436
+    assert checkpoint.config.hidden == 128 and checkpoint.config.layers == 4
+    assert checkpoint.graph_spec.sha256 == GraphSpec.bundled().sha256
+    assert len(checkpoint.weight_pack) == 32 + 4 * 308_484   # params + BN buffers
+    from ginfinity_amd.spec import DATA_DIRECTORY
+    copy = tmp_path / "model"
+    shutil.copytree(DATA_DIRECTORY, copy)
+    payload = bytearray((copy / "encoder.pt").read_bytes())
+    payload[-1] ^= 1
+    (copy / "encoder.pt").write_bytes(payload)
+    with pytest.raises(ModelIntegrityError, match="SHA-256"):
+        load_checkpoint(copy)
+    (copy / "encoder.pt").unlink()
+    with pytest.raises(ModelIntegrityError, match="missing checkpoint"):
+        load_checkpoint(copy)
+
+
+def test_device_policy_has_no_cpu_compute_path():
+    with pytest.raises(ValueError, match="no CPU compute path"):
+        Ginfinity.load("cpu")
+    with pytest.raises(ValueError, match="device must be"):
+        Ginfinity.load("tpu")
+    assert set(default_alignment_parameters()) == {
+        "mu", "sigma", "gamma", "score_min", "score_max", "gap_open", "gap_extend",
+        "score_offset"}
+
+
+def test_microbatch_bounds_semantics():
+    assert microbatch_bounds([8, 8], [30, 30], 8, 30) == [(0, 1), (1, 2)]
+    assert microbatch_bounds([8, 8], [30, 30], 16, 60) == [(0, 2)]
+    assert microbatch_bounds([8, 8, 8], [30, 30, 30], 16, 59) == [(0, 1), (1, 2), (2, 3)]
+    # an oversized single record still forms its own batch (limits are checked earlier)
+    assert microbatch_bounds([20, 3], [5, 5], 10, 10) == [(0, 1), (1, 2)]
+
+
+def test_cli_host_only_commands(tmp_path, capsys):
+    source = tmp_path / "m.tsv"
+    source.write_text("transcript_id\tsequence\tsecondary_structure\n"
+                      "rna-1\tACGUACGU\t((....))\nrna-2\tGGAACCUU\t........\n")
+    graphs, meta = tmp_path / "g.safetensors", tmp_path / "g.json"
+    assert main(["build-graphs", "--input", str(source), "--output", str(graphs),
+                 "--metadata", str(meta), "--checksum"]) == 0
+    out = json.loads(capsys.readouterr().out)
+    assert out["records"] == 2 and out["nodes"] == 16 and out["checksum"] is True
+    assert load_graph_shard(graphs, metadata_path=meta, verify_checksum=True).record_count == 2
+    target = tmp_path / "a.json"
+    assert main(["alignment-config", "--output", str(target)]) == 0
+    assert json.loads(target.read_text())["scoring_parameters"]["sigma"] == 1.0
+    # any failure → message on stderr, exit code 2 (reference cli.py:299-301)
+    assert main(["build-graphs", "--input", str(tmp_path / "missing.tsv"),
+                 "--output", str(graphs)]) == 2
+    assert "ginfinity:" in capsys.readouterr().err
