@@ -39,14 +39,19 @@ def _stale(target: Path, deps: list[Path]) -> bool:
     return any(dep.stat().st_mtime > stamp for dep in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
+def build(force: bool = False, verbose: bool = False, stamps: bool = False) -> Path:
+    """``stamps=True`` builds the diagnostic variant libgfy_stamps.so (per-phase
+    s_memtime totals in the layer kernel); the product library never has them."""
     hipcc = _hipcc()
     headers = list(CSRC.glob("*.h")) + [CSRC.parents[1] / "include" / "gfy.h"]
+    suffix = ".stamps.o" if stamps else ".o"
+    library = CSRC / "libgfy_stamps.so" if stamps else LIBRARY
+    extra = ("-DGFY_STAMPS",) if stamps else ()
     jobs = []
     for name in SOURCES:
-        source, obj = CSRC / name, CSRC / (Path(name).stem + ".o")
+        source, obj = CSRC / name, CSRC / (Path(name).stem + suffix)
         if force or _stale(obj, [source, *headers]):
-            jobs.append([hipcc, *FLAGS, "-c", str(source), "-o", str(obj)])
+            jobs.append([hipcc, *FLAGS, *extra, "-c", str(source), "-o", str(obj)])
 
     def run(cmd):
         if verbose:
@@ -59,16 +64,18 @@ def build(force: bool = False, verbose: bool = False) -> Path:
 
     with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as pool:
         list(pool.map(run, jobs))
-    objects = [CSRC / (Path(name).stem + ".o") for name in SOURCES]
-    if force or jobs or _stale(LIBRARY, objects):
+    objects = [CSRC / (Path(name).stem + suffix) for name in SOURCES]
+    if force or jobs or _stale(library, objects):
         run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}",
-             "-o", str(LIBRARY), *map(str, objects)])
-    return LIBRARY
+             "-o", str(library), *map(str, objects)])
+    return library
 
 
 if __name__ == "__main__":
     parser = argparse.ArgumentParser()
     parser.add_argument("--force", action="store_true")
     parser.add_argument("--verbose", action="store_true")
+    parser.add_argument("--stamps", action="store_true",
+                        help="diagnostic build with in-kernel phase stamps")
     args = parser.parse_args()
-    print(build(args.force, args.verbose))
+    print(build(args.force, args.verbose, args.stamps))

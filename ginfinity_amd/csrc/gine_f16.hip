@@ -45,7 +45,15 @@ constexpr int kLdsB0 = kLdsTable + kMaxEdgeTypes * kHidden * 2;
 constexpr int kLdsAlpha = kLdsB0 + kMlp * 2;
 constexpr int kLdsShift = kLdsAlpha + kMlp * 4;
 constexpr int kLdsB1 = kLdsShift + kMlp * 4;
-constexpr int kLdsLayerBytes = kLdsB1 + kHidden * 2;
+// CSR slice of a tile, double-buffered (tile t is consumed while t+1 is fetched)
+constexpr int kMetaCap = 1024;                    // in-edges of one 64-node tile held in LDS
+constexpr int kMetaRp = 0;                        // int[80]   row_ptr[base .. base+64]
+constexpr int kMetaCol = 320;                     // int[kMetaCap]
+constexpr int kMetaTyp = kMetaCol + kMetaCap * 4; // u8[kMetaCap]
+constexpr int kMetaBytes = kMetaTyp + kMetaCap;
+constexpr int kLdsMeta = kLdsB1 + kHidden * 2;
+constexpr int kLdsLayerBytes = kLdsMeta + 2 * kMetaBytes;
+constexpr int kGatherSlots = 8;                   // neighbour rows in flight per node row
 
 // 16-byte chunk `chunk` of row `row`, XOR-swizzled so that the 16 lanes of one
 // ds_read_b128 lane group (16 distinct rows, same chunk) hit 16 different slots.
@@ -64,6 +72,35 @@ __device__ __forceinline__ f16x8 zero8() {
   f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
   return z;
 }
+
+// Sum over the 16 lanes of a DPP row (the 16 lanes that share one node row), result in
+// every lane.  quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror:
+// pure VALU cross-lane moves — __shfl_xor would go through LDS (ds_bpermute), four
+// dependent round trips per reduction.
+template <int kCtrl>
+__device__ __forceinline__ double dpp_move(double v) {
+  const unsigned long long bits = __builtin_bit_cast(unsigned long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)bits, kCtrl, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(bits >> 32), kCtrl, 0xF, 0xF, false);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double row16_sum(double v) {
+  v += dpp_move<0xB1>(v);    // lane ^ 1
+  v += dpp_move<0x4E>(v);    // lane ^ 2
+  v += dpp_move<0x141>(v);   // row_half_mirror: i <-> 7 - i
+  v += dpp_move<0x140>(v);   // row_mirror:      i <-> 15 - i
+  return v;
+}
+
+#ifdef GFY_STAMPS
+// Diagnostic build only (python -m ginfinity_amd.build --stamps): per-phase
+// shader-clock totals of the layer kernel, one row per workgroup.  Never compiled
+// into libgfy.so proper.
+__device__ unsigned long long g_stamps[256][8];
+#define STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define STAMP(var)
+#endif
 
 // tiles owned by workgroup b: XCD (b & 7) owns tiles [xcd*tpx, (xcd+1)*tpx)
 struct TileWalk {
@@ -161,11 +198,51 @@ __global__ __launch_bounds__(kThreads, 2) void k_gine_layer_f16(
   const f16 scale16 = (f16)p.scale;
   __syncthreads();
 
-  for (TileWalk walk(num_tiles); walk.valid(num_tiles); walk.next()) {
+  // ---- CSR slice of the first tile -> LDS (two dependent loads, paid once) --------
+  TileWalk walk(num_tiles);
+  int buf = 0;
+  if (walk.valid(num_tiles)) {
+    char* meta = smem + kLdsMeta;
     const int base = walk.tile() * kTile;
+    if (t <= kTile) {
+      const int node = base + t < n ? base + t : n;
+      reinterpret_cast<int*>(meta + kMetaRp)[t] = row_ptr[node];
+    }
+    __syncthreads();
+    const int e0 = reinterpret_cast<const int*>(meta + kMetaRp)[0];
+    const int cnt = reinterpret_cast<const int*>(meta + kMetaRp)[kTile] - e0;
+    if (cnt <= kMetaCap)
+      for (int i = t; i < cnt; i += kThreads) {
+        reinterpret_cast<int*>(meta + kMetaCol)[i] = col[e0 + i];
+        reinterpret_cast<uint8_t*>(meta + kMetaTyp)[i] = typ[e0 + i];
+      }
+    __syncthreads();
+  }
+
+  for (; walk.valid(num_tiles); walk.next(), buf ^= 1) {
+    const int base = walk.tile() * kTile;
+    const char* meta = smem + kLdsMeta + buf * kMetaBytes;
+    char* meta_next = smem + kLdsMeta + (buf ^ 1) * kMetaBytes;
+    STAMP(st0);
+    TileWalk ahead = walk;
+    ahead.next();
+    const bool has_next = ahead.valid(num_tiles);
+    const int next_base = ahead.tile() * kTile;
     f16x8 hself[2];
 
+    // row_ptr of the NEXT tile: issued now, parked in LDS after the gather
+    int rp_next = 0;
+    if (has_next && t <= kTile) {
+      const int node = next_base + t < n ? next_base + t : n;
+      rp_next = row_ptr[node];
+    }
+
     // ---- A: gather-sum -> z --------------------------------------------------
+    const int* rp = reinterpret_cast<const int*>(meta + kMetaRp);
+    const int e_base = rp[0];
+    const bool staged = rp[kTile] - e_base <= kMetaCap;   // tile's edges are in LDS
+    const int* col_l = reinterpret_cast<const int*>(meta + kMetaCol);
+    const uint8_t* typ_l = reinterpret_cast<const uint8_t*>(meta + kMetaTyp);
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       const int row = pass * 32 + rsub;
@@ -173,38 +250,59 @@ __global__ __launch_bounds__(kThreads, 2) void k_gine_layer_f16(
       f16x8 z = zero8();
       hself[pass] = zero8();
       if (node < n) {
-        const int lo = row_ptr[node], hi = row_ptr[node + 1];
+        const int lo = rp[row], hi = rp[row + 1];
         const f16x8 hs = *reinterpret_cast<const f16x8*>(
             h_in + (size_t)node * kHidden + chunk * 8);
         float acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;
         int e = lo;
-        for (; e + 1 < hi; e += 2) {  // two rows in flight
-          const int s0 = col[e], s1 = col[e + 1];
-          const int t0 = typ[e], t1 = typ[e + 1];
-          const f16x8 h0 = *reinterpret_cast<const f16x8*>(
-              h_in + (size_t)s0 * kHidden + chunk * 8);
-          const f16x8 h1 = *reinterpret_cast<const f16x8*>(
-              h_in + (size_t)s1 * kHidden + chunk * 8);
-          const f16x8 e0 = *reinterpret_cast<const f16x8*>(table + t0 * kHidden + chunk * 8);
-          const f16x8 e1 = *reinterpret_cast<const f16x8*>(table + t1 * kHidden + chunk * 8);
-          const f16x8 m0 = __builtin_elementwise_max(h0 + e0, zero8());
-          const f16x8 m1 = __builtin_elementwise_max(h1 + e1, zero8());
+        if (staged) {
+          // every in-edge's source row is requested before the first one is used
+          f16x8 hv[kGatherSlots];
+          int ty[kGatherSlots];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[j] += (float)m0[j];
+          for (int i = 0; i < kGatherSlots; ++i) {
+            hv[i] = zero8();
+            ty[i] = 0;
+            if (lo + i < hi) {
+              const int s_i = col_l[lo - e_base + i];
+              ty[i] = typ_l[lo - e_base + i];
+              hv[i] = *reinterpret_cast<const f16x8*>(
+                  h_in + (size_t)s_i * kHidden + chunk * 8);
+            }
+          }
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[j] += (float)m1[j];
-        }
-        if (e < hi) {
-          const int s0 = col[e];
-          const int t0 = typ[e];
-          const f16x8 h0 = *reinterpret_cast<const f16x8*>(
-              h_in + (size_t)s0 * kHidden + chunk * 8);
-          const f16x8 e0 = *reinterpret_cast<const f16x8*>(table + t0 * kHidden + chunk * 8);
-          const f16x8 m0 = __builtin_elementwise_max(h0 + e0, zero8());
+          for (int i = 0; i < kGatherSlots; ++i) {
+            if (lo + i < hi) {   // COO order: slot i is the i-th in-edge
+              const f16x8 ev = *reinterpret_cast<const f16x8*>(table + ty[i] * kHidden + chunk * 8);
+              const f16x8 m = __builtin_elementwise_max(hv[i] + ev, zero8());
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[j] += (float)m0[j];
+              for (int j = 0; j < 8; ++j) acc[j] += (float)m[j];
+            }
+          }
+          e = lo + kGatherSlots;
+          for (; e < hi; ++e) {  // in-degree > 8: rest of the row, still from LDS
+            const int s0 = col_l[e - e_base];
+            const int t0 = typ_l[e - e_base];
+            const f16x8 h0 = *reinterpret_cast<const f16x8*>(
+                h_in + (size_t)s0 * kHidden + chunk * 8);
+            const f16x8 ev = *reinterpret_cast<const f16x8*>(table + t0 * kHidden + chunk * 8);
+            const f16x8 m0 = __builtin_elementwise_max(h0 + ev, zero8());
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += (float)m0[j];
+          }
+        } else {
+          for (; e < hi; ++e) {  // oversized tile (hubs): CSR straight from memory
+            const int s0 = col[e];
+            const int t0 = typ[e];
+            const f16x8 h0 = *reinterpret_cast<const f16x8*>(
+                h_in + (size_t)s0 * kHidden + chunk * 8);
+            const f16x8 ev = *reinterpret_cast<const f16x8*>(table + t0 * kHidden + chunk * 8);
+            const f16x8 m0 = __builtin_elementwise_max(h0 + ev, zero8());
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += (float)m0[j];
+          }
         }
         f16x8 agg;
 #pragma unroll
@@ -214,7 +312,30 @@ __global__ __launch_bounds__(kThreads, 2) void k_gine_layer_f16(
       }
       *reinterpret_cast<f16x8*>(zw + off256(row, chunk)) = z;
     }
+    STAMP(st_a0);
+    if (has_next && t <= kTile) reinterpret_cast<int*>(meta_next + kMetaRp)[t] = rp_next;
     __syncthreads();
+    STAMP(st1);
+
+    // col/typ of the NEXT tile: issued before the GEMMs, parked in LDS after phase D
+    int cn[2] = {0, 0};
+    int tn[2] = {0, 0};
+    int cnt_next = 0;
+    if (has_next) {
+      const int* rpn = reinterpret_cast<const int*>(meta_next + kMetaRp);
+      const int e0n = rpn[0];
+      cnt_next = rpn[kTile] - e0n;
+      if (cnt_next <= kMetaCap) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int i = t + k * kThreads;
+          if (i < cnt_next) {
+            cn[k] = col[e0n + i];
+            tn[k] = typ[e0n + i];
+          }
+        }
+      }
+    }
 
     // ---- B: U^T = W0 . Z^T ; v = relu(R(BN(R(u + b0)))) -------------------------
     {
@@ -247,6 +368,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_gine_layer_f16(
       }
     }
     __syncthreads();
+    STAMP(st2);
 
     // ---- C: W^T = W1 . V^T ; w = R(acc + b1) --------------------------------------
     {
@@ -269,6 +391,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_gine_layer_f16(
       }
     }
     __syncthreads();
+    STAMP(st3);
 
     // ---- D: LayerNorm, residual, store -----------------------------------------
 #pragma unroll
@@ -283,8 +406,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_gine_layer_f16(
         xf[j] = (float)w8[j];
         sum += (double)xf[j];
       }
-#pragma unroll
-      for (int m = 1; m < 16; m <<= 1) sum += __shfl_xor(sum, m, 64);
+      sum = row16_sum(sum);
       const double mean64 = sum * (1.0 / kHidden);
       double sq = 0.0;
 #pragma unroll
@@ -292,8 +414,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_gine_layer_f16(
         const double d = (double)xf[j] - mean64;
         sq += d * d;
       }
-#pragma unroll
-      for (int m = 1; m < 16; m <<= 1) sq += __shfl_xor(sq, m, 64);
+      sq = row16_sum(sq);
       const float var = (float)(sq * (1.0 / kHidden));
       const float mean = (float)mean64;
       const float rstd = 1.0f / __builtin_sqrtf(var + 1e-5f);
@@ -307,7 +428,30 @@ __global__ __launch_bounds__(kThreads, 2) void k_gine_layer_f16(
       if (node < n)
         *reinterpret_cast<f16x8*>(h_out + (size_t)node * kHidden + chunk * 8) = hn;
     }
-    __syncthreads();  // zw is rewritten by the next tile's gather
+    if (has_next && cnt_next <= kMetaCap) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int i = t + k * kThreads;
+        if (i < cnt_next) {
+          reinterpret_cast<int*>(meta_next + kMetaCol)[i] = cn[k];
+          reinterpret_cast<uint8_t*>(meta_next + kMetaTyp)[i] = (uint8_t)tn[k];
+        }
+      }
+    }
+    __syncthreads();  // zw is rewritten by the next tile's gather; next meta is complete
+#ifdef GFY_STAMPS
+    {
+      STAMP(st4);
+      if (t == 0 && blockIdx.x < 256) {
+        g_stamps[blockIdx.x][0] += st_a0 - st0;   // gather, this wave
+        g_stamps[blockIdx.x][1] += st1 - st_a0;   // wait at the A->B barrier
+        g_stamps[blockIdx.x][2] += st2 - st1;     // GEMM1 + epilogue + barrier
+        g_stamps[blockIdx.x][3] += st3 - st2;     // GEMM2 + epilogue + barrier
+        g_stamps[blockIdx.x][4] += st4 - st3;     // LayerNorm + store + barrier
+        g_stamps[blockIdx.x][5] += 1;             // tiles
+      }
+    }
+#endif
   }
 }
 
@@ -448,8 +592,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_head_f16(
         v[j] = (double)(float)o8[j];
         ss += v[j] * v[j];
       }
-#pragma unroll
-      for (int m = 1; m < 16; m <<= 1) ss += __shfl_xor(ss, m, 64);
+      ss = row16_sum(ss);
       if (normalise) {
         const double nrm = __builtin_sqrt(ss);
         const double den = nrm > 1e-12 ? nrm : 1e-12;
@@ -482,6 +625,19 @@ int persistent_grid(int num_tiles) {
 
 }  // namespace
 
+#ifdef GFY_STAMPS
+extern "C" int gfy_debug_stamps(unsigned long long* host /*[256][8]*/, int reset) {
+  if (host && hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) != hipSuccess)
+    return GFY_ERR_HIP;
+  if (reset) {
+    static unsigned long long zeros[256][8] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zeros, sizeof(zeros)) != hipSuccess)
+      return GFY_ERR_HIP;
+  }
+  return GFY_OK;
+}
+#endif
+
 size_t encode_f16_workspace_bytes(int64_t n, int64_t /*e*/) {
   return 2 * align_up((size_t)n * kHidden * sizeof(f16), 256);
 }
@@ -507,6 +663,16 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
       x, enc->f16.w_in, enc->f16.b_in, ha, (int)n);
   enc->mark(s, 1);
   const int stop = tap_stage >= 0 ? tap_stage : enc->layers;
+  static bool lds_opt_in = false;   // > 64 KB of dynamic LDS needs an explicit opt-in
+  if (!lds_opt_in) {
+    GFY_CHECK_HIP(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&k_gine_layer_f16<true>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLayerBytes));
+    GFY_CHECK_HIP(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&k_gine_layer_f16<false>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLayerBytes));
+    lds_opt_in = true;
+  }
   for (int l = 0; l < stop; ++l) {
     if (enc->residual)
       k_gine_layer_f16<true><<<grid, kThreads, kLdsLayerBytes, s>>>(

@@ -8,6 +8,9 @@
 #include <random>
 #include <vector>
 #include "gfy.h"
+#ifdef GFY_STAMPS
+extern "C" int gfy_debug_stamps(unsigned long long*, int);
+#endif
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 #define GK(x) do { int s_ = (x); if (s_ != 0) { printf("gfy error %d: %s (line %d)\n", s_, gfy_last_error(), __LINE__); exit(1);} } while (0)
@@ -99,6 +102,23 @@ int main(int argc, char** argv) {
   printf("per-kernel us:");
   for (int k = 0; k < cnt; ++k) printf(" %.1f", 1e3 * sum[k] / 50);
   printf("\n");
+#ifdef GFY_STAMPS
+  {
+    static unsigned long long st[256][8];
+    gfy_debug_stamps(nullptr, 1);
+    const int reps = 20;
+    for (int i = 0; i < reps; ++i)
+      GK(gfy_encode(enc, dx, drp, dcol, dtyp, N, E, nullptr, dout, GFY_F16, 1, ws2, b2, s));
+    CK(hipStreamSynchronize(s));
+    gfy_debug_stamps(&st[0][0], 0);
+    double sum[6] = {0};
+    for (int b = 0; b < 256; ++b) for (int k = 0; k < 6; ++k) sum[k] += (double)st[b][k];
+    const double tiles = sum[5];
+    printf("layer-kernel phases, shader cycles per tile (mean over %d tiles): gather %.0f | A->B barrier wait %.0f | GEMM1 %.0f | GEMM2 %.0f | LN+store %.0f | total %.0f\n",
+           (int)tiles, sum[0] / tiles, sum[1] / tiles, sum[2] / tiles, sum[3] / tiles, sum[4] / tiles,
+           (sum[0] + sum[1] + sum[2] + sum[3] + sum[4]) / tiles);
+  }
+#endif
   gfy_encoder_destroy(enc);
   return 0;
 }
