@@ -43,7 +43,8 @@ def build(force: bool = False, verbose: bool = False, stamps: bool = False) -> P
     """``stamps=True`` builds the diagnostic variant libgfy_stamps.so (per-phase
     s_memtime totals in the layer kernel); the product library never has them."""
     hipcc = _hipcc()
-    headers = list(CSRC.glob("*.h")) + [CSRC.parents[1] / "include" / "gfy.h"]
+    headers = (list(CSRC.glob("*.h")) + list(CSRC.glob("*.inc"))
+               + [CSRC.parents[1] / "include" / "gfy.h"])
     suffix = ".stamps.o" if stamps else ".o"
     library = CSRC / "libgfy_stamps.so" if stamps else LIBRARY
     extra = ("-DGFY_STAMPS",) if stamps else ()

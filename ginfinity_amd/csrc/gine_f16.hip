@@ -29,6 +29,8 @@
 // The node index sits on the MFMA lane (C^T form), so each lane's 4 consecutive
 // accumulator registers are 4 consecutive channels of one node: 8-byte LDS
 // writes, no transposition.
+#include <cstdlib>
+
 #include "gfy_common.h"
 
 namespace gfy {
@@ -54,6 +56,7 @@ constexpr int kMetaBytes = kMetaTyp + kMetaCap;
 constexpr int kLdsMeta = kLdsB1 + kHidden * 2;
 constexpr int kLdsLayerBytes = kLdsMeta + 2 * kMetaBytes;
 constexpr int kGatherSlots = 8;                   // neighbour rows in flight per node row
+constexpr int kSlotsA = 6;                        // ... in the single-role kernel (2 rows per thread)
 
 // 16-byte chunk `chunk` of row `row`, XOR-swizzled so that the 16 lanes of one
 // ds_read_b128 lane group (16 distinct rows, same chunk) hit 16 different slots.
@@ -89,6 +92,19 @@ __device__ __forceinline__ double row16_sum(double v) {
   v += dpp_move<0x4E>(v);    // lane ^ 2
   v += dpp_move<0x141>(v);   // row_half_mirror: i <-> 7 - i
   v += dpp_move<0x140>(v);   // row_mirror:      i <-> 15 - i
+  return v;
+}
+
+template <int kCtrl>
+__device__ __forceinline__ float dpp_move32(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), kCtrl, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row16_sum32(float v) {
+  v += dpp_move32<0xB1>(v);
+  v += dpp_move32<0x4E>(v);
+  v += dpp_move32<0x141>(v);
+  v += dpp_move32<0x140>(v);
   return v;
 }
 
@@ -238,79 +254,104 @@ __global__ __launch_bounds__(kThreads, 2) void k_gine_layer_f16(
     }
 
     // ---- A: gather-sum -> z --------------------------------------------------
+    // Both node rows of a thread are fetched before either is reduced, slot fetches
+    // are branch-free (clamped index; a slot beyond the in-degree re-reads the
+    // node's own row, already in flight).  Measured alternatives that did NOT help
+    // (profiles/README.md): staging the tile + a +-2 halo in LDS and reading the
+    // backbone / skip-2 neighbours from there, and a wave-specialised pipeline
+    // (gine_layer_ws.inc).
     const int* rp = reinterpret_cast<const int*>(meta + kMetaRp);
     const int e_base = rp[0];
     const bool staged = rp[kTile] - e_base <= kMetaCap;   // tile's edges are in LDS
     const int* col_l = reinterpret_cast<const int*>(meta + kMetaCol);
     const uint8_t* typ_l = reinterpret_cast<const uint8_t*>(meta + kMetaTyp);
+    const char* hbytes = reinterpret_cast<const char*>(h_in);
+    if (staged) {
+      int lo[2], hi[2];
+      f16x8 hv[2][kSlotsA];
+      int ty[2][kSlotsA];
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      const int row = pass * 32 + rsub;
-      const int node = base + row;
-      f16x8 z = zero8();
-      hself[pass] = zero8();
-      if (node < n) {
-        const int lo = rp[row], hi = rp[row + 1];
-        const f16x8 hs = *reinterpret_cast<const f16x8*>(
-            h_in + (size_t)node * kHidden + chunk * 8);
+      for (int pass = 0; pass < 2; ++pass) {
+        const int row = pass * 32 + rsub;
+        const int node = base + row < n ? base + row : n - 1;
+        lo[pass] = rp[row] - e_base;
+        hi[pass] = base + row < n ? rp[row + 1] - e_base : lo[pass];
+        hself[pass] = *reinterpret_cast<const f16x8*>(
+            hbytes + ((uint32_t)node * 256u + (uint32_t)chunk * 16u));
+#pragma unroll
+        for (int i = 0; i < kSlotsA; ++i) {
+          const bool valid = lo[pass] + i < hi[pass];
+          const int at = valid ? lo[pass] + i : 0;
+          const uint32_t s_i = valid ? (uint32_t)col_l[at] : (uint32_t)node;
+          ty[pass][i] = typ_l[at];
+          hv[pass][i] = *reinterpret_cast<const f16x8*>(
+              hbytes + (s_i * 256u + (uint32_t)chunk * 16u));
+        }
+      }
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const int row = pass * 32 + rsub;
         float acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-        int e = lo;
-        if (staged) {
-          // every in-edge's source row is requested before the first one is used
-          f16x8 hv[kGatherSlots];
-          int ty[kGatherSlots];
 #pragma unroll
-          for (int i = 0; i < kGatherSlots; ++i) {
-            hv[i] = zero8();
-            ty[i] = 0;
-            if (lo + i < hi) {
-              const int s_i = col_l[lo - e_base + i];
-              ty[i] = typ_l[lo - e_base + i];
-              hv[i] = *reinterpret_cast<const f16x8*>(
-                  h_in + (size_t)s_i * kHidden + chunk * 8);
-            }
+        for (int i = 0; i < kSlotsA; ++i) {
+          if (lo[pass] + i < hi[pass]) {   // COO order: slot i is the i-th in-edge
+            const f16x8 ev = *reinterpret_cast<const f16x8*>(
+                table + ty[pass][i] * kHidden + chunk * 8);
+            const f16x8 m = __builtin_elementwise_max(hv[pass][i] + ev, zero8());
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += (float)m[j];
           }
+        }
+        for (int e = lo[pass] + kSlotsA; e < hi[pass]; ++e) {  // in-degree > kSlotsA
+          const uint32_t s0 = (uint32_t)col_l[e];
+          const f16x8 h0 = *reinterpret_cast<const f16x8*>(
+              hbytes + (s0 * 256u + (uint32_t)chunk * 16u));
+          const f16x8 ev = *reinterpret_cast<const f16x8*>(table + typ_l[e] * kHidden + chunk * 8);
+          const f16x8 m0 = __builtin_elementwise_max(h0 + ev, zero8());
 #pragma unroll
-          for (int i = 0; i < kGatherSlots; ++i) {
-            if (lo + i < hi) {   // COO order: slot i is the i-th in-edge
-              const f16x8 ev = *reinterpret_cast<const f16x8*>(table + ty[i] * kHidden + chunk * 8);
-              const f16x8 m = __builtin_elementwise_max(hv[i] + ev, zero8());
-#pragma unroll
-              for (int j = 0; j < 8; ++j) acc[j] += (float)m[j];
-            }
-          }
-          e = lo + kGatherSlots;
-          for (; e < hi; ++e) {  // in-degree > 8: rest of the row, still from LDS
-            const int s0 = col_l[e - e_base];
-            const int t0 = typ_l[e - e_base];
-            const f16x8 h0 = *reinterpret_cast<const f16x8*>(
-                h_in + (size_t)s0 * kHidden + chunk * 8);
-            const f16x8 ev = *reinterpret_cast<const f16x8*>(table + t0 * kHidden + chunk * 8);
-            const f16x8 m0 = __builtin_elementwise_max(h0 + ev, zero8());
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += (float)m0[j];
-          }
-        } else {
-          for (; e < hi; ++e) {  // oversized tile (hubs): CSR straight from memory
-            const int s0 = col[e];
-            const int t0 = typ[e];
-            const f16x8 h0 = *reinterpret_cast<const f16x8*>(
-                h_in + (size_t)s0 * kHidden + chunk * 8);
-            const f16x8 ev = *reinterpret_cast<const f16x8*>(table + t0 * kHidden + chunk * 8);
-            const f16x8 m0 = __builtin_elementwise_max(h0 + ev, zero8());
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += (float)m0[j];
-          }
+          for (int j = 0; j < 8; ++j) acc[j] += (float)m0[j];
         }
         f16x8 agg;
 #pragma unroll
         for (int j = 0; j < 8; ++j) agg[j] = (f16)acc[j];   // ONE rounding of the fp32 sum
-        z = hs * scale16 + agg;   // R(R(s*h) + a): two fp16 ops (contraction is off)
-        hself[pass] = hs;
+        f16x8 z = hself[pass] * scale16 + agg;   // R(R(s*h) + a): two fp16 ops
+        if (base + row >= n) {
+          z = zero8();
+          hself[pass] = zero8();
+        }
+        *reinterpret_cast<f16x8*>(zw + off256(row, chunk)) = z;
       }
-      *reinterpret_cast<f16x8*>(zw + off256(row, chunk)) = z;
+    } else {
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {   // oversized tile (hubs): CSR from memory
+        const int row = pass * 32 + rsub;
+        const int node = base + row;
+        f16x8 z = zero8();
+        hself[pass] = zero8();
+        if (node < n) {
+          const f16x8 hs = *reinterpret_cast<const f16x8*>(
+              h_in + (size_t)node * kHidden + chunk * 8);
+          float acc[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+          for (int e = rp[row]; e < rp[row + 1]; ++e) {
+            const f16x8 h0 = *reinterpret_cast<const f16x8*>(
+                h_in + (size_t)col[e] * kHidden + chunk * 8);
+            const f16x8 ev = *reinterpret_cast<const f16x8*>(table + typ[e] * kHidden + chunk * 8);
+            const f16x8 m0 = __builtin_elementwise_max(h0 + ev, zero8());
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += (float)m0[j];
+          }
+          f16x8 agg;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) agg[j] = (f16)acc[j];
+          z = hs * scale16 + agg;
+          hself[pass] = hs;
+        }
+        *reinterpret_cast<f16x8*>(zw + off256(row, chunk)) = z;
+      }
     }
     STAMP(st_a0);
     if (has_next && t <= kTile) reinterpret_cast<int*>(meta_next + kMetaRp)[t] = rp_next;
@@ -400,23 +441,21 @@ __global__ __launch_bounds__(kThreads, 2) void k_gine_layer_f16(
       const int node = base + row;
       const f16x8 w8 = *reinterpret_cast<const f16x8*>(zw + off256(row, chunk));
       float xf[8];
-      double sum = 0.0;
+      float sum = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         xf[j] = (float)w8[j];
-        sum += (double)xf[j];
+        sum += xf[j];
       }
-      sum = row16_sum(sum);
-      const double mean64 = sum * (1.0 / kHidden);
-      double sq = 0.0;
+      // two-pass fp32 moments over the 16 lanes of the row (DPP, no LDS round trip)
+      const float mean = row16_sum32(sum) * (1.0f / kHidden);
+      float sq = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const double d = (double)xf[j] - mean64;
-        sq += d * d;
+        const float d = xf[j] - mean;
+        sq = __builtin_fmaf(d, d, sq);
       }
-      sq = row16_sum(sq);
-      const float var = (float)(sq * (1.0 / kHidden));
-      const float mean = (float)mean64;
+      const float var = row16_sum32(sq) * (1.0f / kHidden);
       const float rstd = 1.0f / __builtin_sqrtf(var + 1e-5f);
       const float offset = -rstd * mean;
       f16x8 y;
@@ -454,6 +493,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_gine_layer_f16(
 #endif
   }
 }
+
+#include "gine_layer_ws.inc"
 
 // ---------------------------------------------------------------------------------
 // head + normalise
@@ -652,10 +693,15 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
   const size_t need = encode_f16_workspace_bytes(n, e);
   GFY_REQUIRE(ws_bytes >= need, GFY_ERR_WORKSPACE,
               "gfy_encode: workspace %zu < required %zu", ws_bytes, need);
+  GFY_REQUIRE(n <= (int64_t)1 << 24, GFY_ERR_UNSUPPORTED,
+              "gfy_encode: fp16 path addresses rows with 32-bit byte offsets; "
+              "split micro-batches above 16,777,216 nodes (got %lld)", (long long)n);
   f16* ha = (f16*)ws;
   f16* hb = (f16*)((char*)ws + need / 2);
   const int num_tiles = (int)((n + kTile - 1) / kTile);
   const int grid = persistent_grid(num_tiles);
+  const int ws_tiles = (int)((n + kWt - 1) / kWt);
+  const int ws_grid = persistent_grid(ws_tiles);
 
   const int64_t items = n * 16;
   enc->mark(s, 0);
@@ -663,8 +709,20 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
       x, enc->f16.w_in, enc->f16.b_in, ha, (int)n);
   enc->mark(s, 1);
   const int stop = tap_stage >= 0 ? tap_stage : enc->layers;
+  // GFY_LAYER_KERNEL=ws selects the experimental wave-specialised kernel
+  // (gine_layer_ws.inc: correct, currently slower — kept for A/B runs)
+  static const bool use_ws = [] {
+    const char* v = getenv("GFY_LAYER_KERNEL");
+    return v && v[0] == 'w';
+  }();
   static bool lds_opt_in = false;   // > 64 KB of dynamic LDS needs an explicit opt-in
   if (!lds_opt_in) {
+    GFY_CHECK_HIP(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&k_gine_layer_ws<true>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, kWsBytes));
+    GFY_CHECK_HIP(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&k_gine_layer_ws<false>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, kWsBytes));
     GFY_CHECK_HIP(hipFuncSetAttribute(
         reinterpret_cast<const void*>(&k_gine_layer_f16<true>),
         hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLayerBytes));
@@ -674,7 +732,13 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
     lds_opt_in = true;
   }
   for (int l = 0; l < stop; ++l) {
-    if (enc->residual)
+    if (use_ws && enc->residual)
+      k_gine_layer_ws<true><<<ws_grid, kThreads, kWsBytes, s>>>(
+          enc->f16.layer[l], ha, hb, row_ptr, col, typ, (int)n, ws_tiles);
+    else if (use_ws)
+      k_gine_layer_ws<false><<<ws_grid, kThreads, kWsBytes, s>>>(
+          enc->f16.layer[l], ha, hb, row_ptr, col, typ, (int)n, ws_tiles);
+    else if (enc->residual)
       k_gine_layer_f16<true><<<grid, kThreads, kLdsLayerBytes, s>>>(
           enc->f16.layer[l], ha, hb, row_ptr, col, typ, (int)n, num_tiles);
     else

@@ -111,8 +111,11 @@ int main(int argc, char** argv) {
       GK(gfy_encode(enc, dx, drp, dcol, dtyp, N, E, nullptr, dout, GFY_F16, 1, ws2, b2, s));
     CK(hipStreamSynchronize(s));
     gfy_debug_stamps(&st[0][0], 0);
-    double sum[6] = {0};
-    for (int b = 0; b < 256; ++b) for (int k = 0; k < 6; ++k) sum[k] += (double)st[b][k];
+    double sum[8] = {0};
+    for (int b = 0; b < 256; ++b) for (int k = 0; k < 8; ++k) sum[k] += (double)st[b][k];
+    printf("single-role sub-phases of gather per tile: far scan+issue %.0f | tile landed+LDS write+barrier %.0f\n", sum[6] / sum[5], sum[7] / sum[5]);
+    printf("ws stamps per step: matrix GEMM1 %.0f waitB1 %.0f GEMM2 %.0f waitB2 %.0f | vector first-half %.0f second-half %.0f (steps %.0f)\n",
+           sum[0] / sum[5], sum[1] / sum[5], sum[2] / sum[5], sum[3] / sum[5], sum[4] / sum[5], sum[6] / sum[5], sum[5]);
     const double tiles = sum[5];
     printf("layer-kernel phases, shader cycles per tile (mean over %d tiles): gather %.0f | A->B barrier wait %.0f | GEMM1 %.0f | GEMM2 %.0f | LN+store %.0f | total %.0f\n",
            (int)tiles, sum[0] / tiles, sum[1] / tiles, sum[2] / tiles, sum[3] / tiles, sum[4] / tiles,
