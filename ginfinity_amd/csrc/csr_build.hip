@@ -137,6 +137,16 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_final(
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) row_ptr[n] = offset + total;
 }
 
+// zero the degree counters and the worklist counter in ONE launch (two hipMemsetAsync
+// calls cost three fill kernels)
+__global__ __launch_bounds__(256) void k_zero(int32_t* __restrict__ row_ptr, int64_t count,
+                                              int32_t* __restrict__ big_count) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (i == 0) *big_count = 0;
+  for (; i < count; i += stride) row_ptr[i] = 0;
+}
+
 __global__ __launch_bounds__(256) void k_scatter(
     const int32_t* __restrict__ dst, const int32_t* __restrict__ slot,
     const int32_t* __restrict__ row_ptr, int64_t e_count,
@@ -253,10 +263,11 @@ int launch_build_csr(const int32_t* edge_index, const uint8_t* edge_types,
   const int32_t* dst = edge_index + e;
   const int tiles = (int)((n + kScanTile - 1) / kScanTile);
 
-  GFY_CHECK_HIP(hipMemsetAsync(row_ptr, 0, (size_t)(n + 1) * 4, s));
-  GFY_CHECK_HIP(hipMemsetAsync(w.big_count, 0, 16, s));
+  k_zero<<<grid_for(n + 1, 256, 1024), 256, 0, s>>>(row_ptr, n + 1, w.big_count);
   if (e > 0)
     k_histogram<<<grid_for(e, 256), 256, 0, s>>>(dst, e, n, row_ptr, w.slot);
+  // three small kernels; a single-pass chained scan was measured slower here (17 us:
+  // serial hand-offs between tiles + strided per-thread runs), see profiles/README.md
   k_scan_partial<<<tiles, kScanBlock, 0, s>>>(row_ptr, n, w.sums);
   k_scan_sums<<<1, kScanBlock, 0, s>>>(w.sums, tiles);
   k_scan_final<<<tiles, kScanBlock, 0, s>>>(row_ptr, n, w.sums);

@@ -95,6 +95,15 @@ __device__ __forceinline__ double row16_sum(double v) {
   return v;
 }
 
+// 1/sqrt(x): v_rsq_f32 (1 ulp) + one Newton step -> within ~1 ulp of the correctly
+// rounded value the oracle uses; ~6 instructions instead of the ~40 of the IEEE
+// sqrt + divide sequences, executed redundantly by the 16 lanes of every row.
+__device__ __forceinline__ float fast_rsqrt(float x) {
+  const float r = __builtin_amdgcn_rsqf(x);
+  const float e = __builtin_fmaf(-x * r, r, 1.0f);       // 1 - x r^2
+  return __builtin_fmaf(0.5f * r, e, r);
+}
+
 template <int kCtrl>
 __device__ __forceinline__ float dpp_move32(float v) {
   return __builtin_bit_cast(
@@ -185,19 +194,20 @@ __global__ __launch_bounds__(kThreads, 2) void k_gine_layer_f16(
   const int r = lane & 31, hq = lane >> 5;
   const int chunk = t & 15, rsub = t >> 4;  // gather / LayerNorm mapping
 
-  // per-launch constants -> LDS
-  for (int i = t; i < kMaxEdgeTypes * kHidden / 8; i += kThreads)
-    reinterpret_cast<f16x8*>(table)[i] =
-        reinterpret_cast<const f16x8*>(p.edge_table)[i];
-  if (t < kMlp / 8)
-    reinterpret_cast<f16x8*>(b0s)[t] = reinterpret_cast<const f16x8*>(p.b0)[t];
-  if (t < kMlp / 4) {
-    reinterpret_cast<f32x4*>(alphas)[t] = reinterpret_cast<const f32x4*>(p.bn_alpha)[t];
-    reinterpret_cast<f32x4*>(shifts)[t] = reinterpret_cast<const f32x4*>(p.bn_shift)[t];
+  // Prologue.  Three dependent round trips are unavoidable before the first tile can
+  // be reduced (row_ptr -> col/typ -> neighbour rows, ~1.3 us each under load), so
+  // the row_ptr request goes out first and the per-launch constants and the weight
+  // fragments travel in its shadow (vmcnt retires in order: nothing queued before
+  // row_ptr delays it).
+  STAMP(st_begin);
+  TileWalk walk(num_tiles);
+  int buf = 0;
+  const bool any_tile = walk.valid(num_tiles);
+  int rp_first = 0;
+  if (any_tile && t <= kTile) {
+    const int base0 = walk.tile() * kTile;
+    rp_first = row_ptr[base0 + t < n ? base0 + t : n];
   }
-  if (t < kHidden / 8)
-    reinterpret_cast<f16x8*>(b1s)[t] = reinterpret_cast<const f16x8*>(p.b1)[t];
-
   // weight fragments -> registers, kept for every tile of this workgroup
   f16x8 w0f[8], w1f[16];
   {
@@ -212,19 +222,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_gine_layer_f16(
   const f16x8 gamma8 = reinterpret_cast<const f16x8*>(p.ln_gamma)[chunk];
   const f16x8 beta8 = reinterpret_cast<const f16x8*>(p.ln_beta)[chunk];
   const f16 scale16 = (f16)p.scale;
+  if (any_tile && t <= kTile)
+    reinterpret_cast<int*>(smem + kLdsMeta + kMetaRp)[t] = rp_first;
   __syncthreads();
-
-  // ---- CSR slice of the first tile -> LDS (two dependent loads, paid once) --------
-  TileWalk walk(num_tiles);
-  int buf = 0;
-  if (walk.valid(num_tiles)) {
+  if (any_tile) {   // col/typ of the first tile: second round trip
     char* meta = smem + kLdsMeta;
-    const int base = walk.tile() * kTile;
-    if (t <= kTile) {
-      const int node = base + t < n ? base + t : n;
-      reinterpret_cast<int*>(meta + kMetaRp)[t] = row_ptr[node];
-    }
-    __syncthreads();
     const int e0 = reinterpret_cast<const int*>(meta + kMetaRp)[0];
     const int cnt = reinterpret_cast<const int*>(meta + kMetaRp)[kTile] - e0;
     if (cnt <= kMetaCap)
@@ -232,8 +234,26 @@ __global__ __launch_bounds__(kThreads, 2) void k_gine_layer_f16(
         reinterpret_cast<int*>(meta + kMetaCol)[i] = col[e0 + i];
         reinterpret_cast<uint8_t*>(meta + kMetaTyp)[i] = typ[e0 + i];
       }
-    __syncthreads();
   }
+  // per-launch constants -> LDS
+  for (int i = t; i < kMaxEdgeTypes * kHidden / 8; i += kThreads)
+    reinterpret_cast<f16x8*>(table)[i] =
+        reinterpret_cast<const f16x8*>(p.edge_table)[i];
+  if (t < kMlp / 8)
+    reinterpret_cast<f16x8*>(b0s)[t] = reinterpret_cast<const f16x8*>(p.b0)[t];
+  if (t < kMlp / 4) {
+    reinterpret_cast<f32x4*>(alphas)[t] = reinterpret_cast<const f32x4*>(p.bn_alpha)[t];
+    reinterpret_cast<f32x4*>(shifts)[t] = reinterpret_cast<const f32x4*>(p.bn_shift)[t];
+  }
+  if (t < kHidden / 8)
+    reinterpret_cast<f16x8*>(b1s)[t] = reinterpret_cast<const f16x8*>(p.b1)[t];
+  __syncthreads();
+#ifdef GFY_STAMPS
+  {
+    STAMP(st_pro);
+    if (t == 0 && blockIdx.x < 256) g_stamps[blockIdx.x][6] += st_pro - st_begin;
+  }
+#endif
 
   for (; walk.valid(num_tiles); walk.next(), buf ^= 1) {
     const int base = walk.tile() * kTile;
@@ -380,32 +400,36 @@ __global__ __launch_bounds__(kThreads, 2) void k_gine_layer_f16(
 
     // ---- B: U^T = W0 . Z^T ; v = relu(R(BN(R(u + b0)))) -------------------------
     {
+      // chain 0, then chain 1 with the epilogue of chain 0 in its shadow (an MFMA
+      // holds the issue port for 8 of its 32 cycles)
       f32x16 acc0 = {0}, acc1 = {0};
+      f16x8 z1f[8];
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         const f16x8 z0 = *reinterpret_cast<const f16x8*>(zw + off256(r, 2 * ks + hq));
-        const f16x8 z1 = *reinterpret_cast<const f16x8*>(zw + off256(32 + r, 2 * ks + hq));
+        z1f[ks] = *reinterpret_cast<const f16x8*>(zw + off256(32 + r, 2 * ks + hq));
         acc0 = mfma(w0f[ks], z0, acc0);
-        acc1 = mfma(w0f[ks], z1, acc1);
       }
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int c0 = wave * 32 + 8 * g + 4 * hq;  // 4 consecutive channels
-        const f16x4 b0v = *reinterpret_cast<const f16x4*>(b0s + c0);
-        const f32x4 al = *reinterpret_cast<const f32x4*>(alphas + c0);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(shifts + c0);
-        f16x4 v0, v1;
+      for (int ks = 0; ks < 8; ++ks) acc1 = mfma(w0f[ks], z1f[ks], acc1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const f16 u0 = (f16)(acc0[4 * g + i] + (float)b0v[i]);
-          const f16 u1 = (f16)(acc1[4 * g + i] + (float)b0v[i]);
-          const f16 y0 = (f16)__builtin_fmaf((float)u0, al[i], sh[i]);
-          const f16 y1 = (f16)__builtin_fmaf((float)u1, al[i], sh[i]);
-          v0[i] = y0 > (f16)0 ? y0 : (f16)0;
-          v1[i] = y1 > (f16)0 ? y1 : (f16)0;
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c0 = wave * 32 + 8 * g + 4 * hq;  // 4 consecutive channels
+          const f16x4 b0v = *reinterpret_cast<const f16x4*>(b0s + c0);
+          const f32x4 al = *reinterpret_cast<const f32x4*>(alphas + c0);
+          const f32x4 sh = *reinterpret_cast<const f32x4*>(shifts + c0);
+          f16x4 vv;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float a = half == 0 ? acc0[4 * g + i] : acc1[4 * g + i];
+            const f16 u = (f16)(a + (float)b0v[i]);
+            const f16 y = (f16)__builtin_fmaf((float)u, al[i], sh[i]);
+            vv[i] = y > (f16)0 ? y : (f16)0;
+          }
+          *reinterpret_cast<f16x4*>(vt + off512(32 * half + r, c0 >> 3) + hq * 8) = vv;
         }
-        *reinterpret_cast<f16x4*>(vt + off512(r, c0 >> 3) + hq * 8) = v0;
-        *reinterpret_cast<f16x4*>(vt + off512(32 + r, c0 >> 3) + hq * 8) = v1;
       }
     }
     __syncthreads();
@@ -456,7 +480,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_gine_layer_f16(
         sq = __builtin_fmaf(d, d, sq);
       }
       const float var = row16_sum32(sq) * (1.0f / kHidden);
-      const float rstd = 1.0f / __builtin_sqrtf(var + 1e-5f);
+      const float rstd = fast_rsqrt(var + 1e-5f);
       const float offset = -rstd * mean;
       f16x8 y;
 #pragma unroll
@@ -492,6 +516,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_gine_layer_f16(
     }
 #endif
   }
+#ifdef GFY_STAMPS
+  {
+    STAMP(st_end);
+    if (t == 0 && blockIdx.x < 256) g_stamps[blockIdx.x][7] += st_end - st_begin;
+  }
+#endif
 }
 
 #include "gine_layer_ws.inc"
@@ -571,16 +601,33 @@ __global__ __launch_bounds__(kThreads, 2) void k_head_f16(
     bbv[g] = *reinterpret_cast<const f16x4*>(p.bb + c0);
   }
 
-  for (TileWalk walk(num_tiles); walk.valid(num_tiles); walk.next()) {
-    const int base = walk.tile() * kTile;
+  // rows of the first tile; afterwards every tile's rows are requested one tile
+  // ahead (a round trip costs ~1.3 us under load and would otherwise be exposed)
+  TileWalk walk(num_tiles);
+  f16x8 pre[2] = {zero8(), zero8()};
+  if (walk.valid(num_tiles)) {
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
-      const int row = pass * 32 + rsub;
-      const int node = base + row;
-      f16x8 v = zero8();
+      const int node = walk.tile() * kTile + pass * 32 + rsub;
       if (node < n)
-        v = *reinterpret_cast<const f16x8*>(h + (size_t)node * kHidden + chunk * 8);
-      *reinterpret_cast<f16x8*>(ht + off256(row, chunk)) = v;
+        pre[pass] = *reinterpret_cast<const f16x8*>(h + (size_t)node * kHidden + chunk * 8);
+    }
+  }
+  for (; walk.valid(num_tiles); walk.next()) {
+    const int base = walk.tile() * kTile;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass)
+      *reinterpret_cast<f16x8*>(ht + off256(pass * 32 + rsub, chunk)) = pre[pass];
+    {
+      TileWalk ahead = walk;
+      ahead.next();
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const int node = ahead.tile() * kTile + pass * 32 + rsub;
+        pre[pass] = zero8();
+        if (ahead.valid(num_tiles) && node < n)
+          pre[pass] = *reinterpret_cast<const f16x8*>(h + (size_t)node * kHidden + chunk * 8);
+      }
     }
     __syncthreads();
     {  // t = relu(R(h . Wa^T + ba))                         (_model.py:61-62)
@@ -637,8 +684,16 @@ __global__ __launch_bounds__(kThreads, 2) void k_head_f16(
       if (normalise) {
         const double nrm = __builtin_sqrt(ss);
         const double den = nrm > 1e-12 ? nrm : 1e-12;
+        if constexpr (sizeof(OutT) == 8) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = v[j] / den;
+          for (int j = 0; j < 8; ++j) v[j] = v[j] / den;      // exact quotient for f64 output
+        } else {
+          // one division, eight multiplies: differs from the exact quotient by <= 1 ulp of
+          // float64, invisible after the single rounding to fp16 / fp32
+          const double inv = 1.0 / den;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = v[j] * inv;
+        }
       }
       if (node < n) {
         const int dest = out_rows ? out_rows[node] : node;

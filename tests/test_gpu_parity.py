@@ -20,6 +20,23 @@ def _maxabs(a, b):
     return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())
 
 
+def _concat_shards(a, b):
+    """Two copies of a shard's arrays back to back (identifiers made unique)."""
+    from ginfinity_amd import GraphShard
+    return GraphShard(
+        identifiers=a.identifiers + tuple(i + "#2" for i in b.identifiers),
+        sequences=a.sequences + b.sequences, structures=a.structures + b.structures,
+        node_features=np.concatenate([a.node_features, b.node_features]),
+        edge_index=np.ascontiguousarray(np.concatenate(
+            [a.edge_index, b.edge_index + np.int32(a.node_count)], axis=1)),
+        edge_types=np.concatenate([a.edge_types, b.edge_types]),
+        node_ptr=np.concatenate([a.node_ptr, b.node_ptr[1:] + a.node_ptr[-1]]),
+        edge_ptr=np.concatenate([a.edge_ptr, b.edge_ptr[1:] + a.edge_ptr[-1]]),
+        spec=a.spec,
+        residue_index=np.concatenate([a.residue_index, b.residue_index]),
+        node_roles=np.concatenate([a.node_roles, b.node_roles]))
+
+
 def _device_inputs(encoder, shard):
     import torch
     dev = encoder._engine.device
@@ -300,3 +317,19 @@ def test_fp32_hidden_against_float64_truth(gpu_encoder_fp32, oracle_weights, rou
                           shard.edge_types, dtype=np.float64)
     scale = np.abs(truth).max()
     assert _maxabs(raw, truth) <= 2e-6 * scale
+
+
+def test_csr_large_shards(gpu_encoder, rouskin_shard):
+    """CSR of 1.8M-, 0.9M- and 0.45M-node shards (multi-tile scans, tile-sum scan
+    looping more than once) against the stable-sort oracle."""
+    import torch
+    from oracle import gine_numpy as G
+    big = _concat_shards(rouskin_shard, rouskin_shard)          # 1,795,176 nodes
+    for shard in (big, rouskin_shard, rouskin_shard.slice(0, 3000)):
+        _, ei, et = _device_inputs(gpu_encoder, shard)
+        csr = gpu_encoder._engine.build_csr(ei, et, shard.node_count)
+        row_ptr, col, typ = G.build_csr(shard.edge_index, shard.edge_types, shard.node_count)
+        e = shard.edge_count
+        np.testing.assert_array_equal(csr.row_ptr.cpu().numpy(), row_ptr)
+        np.testing.assert_array_equal(csr.col.cpu().numpy()[:e], col)
+        np.testing.assert_array_equal(csr.typ.cpu().numpy()[:e], typ)

@@ -18,6 +18,7 @@ extern "C" int gfy_debug_stamps(unsigned long long*, int);
 int main(int argc, char** argv) {
   const int64_t N = argc > 1 ? atoll(argv[1]) : 60000;
   const int steps = argc > 2 ? atoi(argv[2]) : 200;
+  const bool no_edges = argc > 3 && argv[3][0] == 'n';   // MLP-only timing
   const int L = 4000;
   std::mt19937 rng(1);
   std::normal_distribution<float> nd(0.f, 1.f);
@@ -57,6 +58,7 @@ int main(int argc, char** argv) {
                                       src.push_back(b + i + 2); dst.push_back(b + i); typ.push_back(5); }
     for (int i = 0; i < 6; ++i) { src.push_back(b + rng() % L); dst.push_back(b + rng() % L); typ.push_back(2); }
   }
+  if (no_edges) { src.resize(1); dst.resize(1); typ.resize(1); }
   const int64_t E = (int64_t)src.size();
   std::vector<int32_t> ei(2 * E);
   memcpy(ei.data(), src.data(), E * 4); memcpy(ei.data() + E, dst.data(), E * 4);
@@ -113,7 +115,13 @@ int main(int argc, char** argv) {
     gfy_debug_stamps(&st[0][0], 0);
     double sum[8] = {0};
     for (int b = 0; b < 256; ++b) for (int k = 0; k < 8; ++k) sum[k] += (double)st[b][k];
-    printf("single-role sub-phases of gather per tile: far scan+issue %.0f | tile landed+LDS write+barrier %.0f\n", sum[6] / sum[5], sum[7] / sum[5]);
+    {
+      const double launches = reps * 4.0 * 256;   // 4 layers, 256 workgroups
+      double tmax = 0, tmin = 1e30;
+      for (int b = 0; b < 256; ++b) { tmax = st[b][7] > tmax ? st[b][7] : tmax; tmin = st[b][7] < tmin ? st[b][7] : tmin; }
+      printf("per workgroup launch: prologue %.0f cycles, whole kernel body %.0f cycles (min WG %.0f, max WG %.0f per launch)\n",
+             sum[6] / launches, sum[7] / launches, tmin / (reps * 4.0), tmax / (reps * 4.0));
+    }
     printf("ws stamps per step: matrix GEMM1 %.0f waitB1 %.0f GEMM2 %.0f waitB2 %.0f | vector first-half %.0f second-half %.0f (steps %.0f)\n",
            sum[0] / sum[5], sum[1] / sum[5], sum[2] / sum[5], sum[3] / sum[5], sum[4] / sum[5], sum[6] / sum[5], sum[5]);
     const double tiles = sum[5];

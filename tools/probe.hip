@@ -80,6 +80,26 @@ __global__ __launch_bounds__(256) void kgs(f16* __restrict__ h, int64_t items) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < items; i += (int64_t)gridDim.x * blockDim.x)
     reinterpret_cast<f16x8*>(h)[i] = out;
 }
+// ---- row-gather micro-benchmark: 7 rows of 256 B per node (self, +-1, +-2, random partner) ----
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void kgather(const f16* __restrict__ h, const int* __restrict__ partner,
+                                                   f16* __restrict__ z, int n) {
+  for (int64_t item = (int64_t)blockIdx.x * THREADS + threadIdx.x; item < (int64_t)n * 16;
+       item += (int64_t)gridDim.x * THREADS) {
+    const int node = (int)(item >> 4), chunk = (int)(item & 15);
+    int nb[6] = {node - 1, node + 1, node - 2, node + 2, partner[node], node};
+    f16x8 v[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      int s = nb[i] < 0 ? 0 : (nb[i] >= n ? n - 1 : nb[i]);
+      v[i] = *reinterpret_cast<const f16x8*>(h + (size_t)s * 128 + chunk * 8);
+    }
+    f16x8 acc = v[0];
+#pragma unroll
+    for (int i = 1; i < 6; ++i) acc += v[i];
+    *reinterpret_cast<f16x8*>(z + (size_t)node * 128 + chunk * 8) = acc;
+  }
+}
 int main() {
   const int n = 60000;
   float* x; f16 *w, *b, *h;
@@ -108,5 +128,17 @@ int main() {
   f16* big; CK(hipMalloc(&big, (size_t)1 << 30));
   int rot = 0;
   timeit("store only, rotating 1GiB", [&] { k<0><<<blocks, 256>>>(x, w, b, big + (size_t)(rot++ % 64) * n * 128, n); });
+  {
+    const int n2 = 60000;
+    f16 *hh, *zz; int* part;
+    CK(hipMalloc(&hh, (size_t)n2 * 256)); CK(hipMalloc(&zz, (size_t)n2 * 256)); CK(hipMalloc(&part, n2 * 4));
+    std::vector<int> pp(n2); for (int i = 0; i < n2; ++i) pp[i] = (int)(((long long)i * 7919 + 13) % n2);
+    CK(hipMemcpy(part, pp.data(), n2 * 4, hipMemcpyHostToDevice)); CK(hipMemset(hh, 0, (size_t)n2 * 256));
+    timeit("gather 60k x6 rows, 3750 blk x256", [&] { kgather<256><<<3750, 256>>>(hh, part, zz, n2); });
+    timeit("gather 60k x6 rows, 2048 blk x256", [&] { kgather<256><<<2048, 256>>>(hh, part, zz, n2); });
+    timeit("gather 60k x6 rows, 256 blk x512", [&] { kgather<512><<<256, 512>>>(hh, part, zz, n2); });
+    timeit("gather 60k x6 rows, 512 blk x512", [&] { kgather<512><<<512, 512>>>(hh, part, zz, n2); });
+    timeit("gather 60k x6 rows, 1024 blk x512", [&] { kgather<512><<<1024, 512>>>(hh, part, zz, n2); });
+  }
   return 0;
 }
