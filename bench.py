@@ -52,6 +52,8 @@ def parse() -> argparse.Namespace:
     parser.add_argument("--gpus", type=int, default=1)
     parser.add_argument("--steps", type=int, default=200)
     parser.add_argument("--warmup", type=int, default=20)
+    parser.add_argument("--streams", type=int, default=4,
+                        help="independent shards in flight per GPU (HIP streams)")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--cpu-seconds", type=float, default=12.0)
     return parser.parse_args()
@@ -93,8 +95,13 @@ def main() -> None:
     torch.cuda.set_device(device)
 
     from ginfinity_amd import Ginfinity, synthetic
-    encoder = Ginfinity.load(f"cuda:{local_rank}")
-    engine = encoder._engine
+    # one encoder handle (weights + workspace) per stream: shards are independent, so
+    # several are kept in flight to cover launch gaps and per-kernel prologues/tails
+    lanes = max(1, args.streams)
+    encoders = [Ginfinity.load(f"cuda:{local_rank}") for _ in range(lanes)]
+    engines = [e._engine for e in encoders]
+    streams = [torch.cuda.Stream(device=device) for _ in range(lanes)]
+    engine = engines[0]
 
     # inputs resident in HBM before the timed region
     shards = [synthetic.roofline_shard(1000 * rank + i) for i in range(POOL)]
@@ -103,12 +110,15 @@ def main() -> None:
                torch.from_numpy(s.edge_index).to(device),
                torch.from_numpy(s.edge_types).to(device)) for s in shards]
     outputs = [torch.empty((NODES, 128), dtype=torch.float16, device=device)
-               for _ in range(POOL)]
+               for _ in range(max(POOL, lanes))]
+    csrs = [None] * lanes        # per-lane CSR buffers, reused every step
 
     def step(i: int) -> None:
         x, ei, et = inputs[i % POOL]
-        csr = engine.build_csr(ei, et, NODES)
-        engine.encode(x, csr, out=outputs[i % POOL])
+        lane = i % lanes
+        with torch.cuda.stream(streams[lane]):
+            csrs[lane] = engines[lane].build_csr(ei, et, NODES, out=csrs[lane])
+            engines[lane].encode(x, csrs[lane], out=outputs[lane])
 
     def fence() -> None:
         if distributed:
@@ -182,7 +192,8 @@ def main() -> None:
                                    "max_batch_edges=300000 (BASELINE configs[2]), "
                                    "fp16 model, fp16 normalised output",
                        "nodes_per_step": NODES, "edges_per_step": EDGES,
-                       "shards_per_rank": POOL, "parallelism": f"shard-parallel x{world}"},
+                       "shards_per_rank": POOL, "streams_per_gpu": lanes,
+                       "parallelism": f"shard-parallel x{world}"},
             "roofline": roofline, "cpu_baseline": baseline, "kernels_ms": kernels,
         }))
     if distributed:

@@ -96,16 +96,21 @@ class DeviceEncoder:
 
     # -- kernels ----------------------------------------------------------------------
     def build_csr(self, edge_index: torch.Tensor, edge_types: torch.Tensor,
-                  nodes: int) -> DeviceCsr:
-        """COO (int32 [2,E], uint8 [E]) → destination-major CSR on the device."""
+                  nodes: int, *, out: DeviceCsr | None = None) -> DeviceCsr:
+        """COO (int32 [2,E], uint8 [E]) → destination-major CSR on the device.
+        ``out`` reuses the buffers of an earlier CSR of the same size (steady-state
+        loops: no allocator traffic)."""
         edges = int(edge_types.numel())
         assert edge_index.dtype == torch.int32 and edge_index.is_contiguous()
         assert edge_types.dtype == torch.uint8 and edge_types.is_contiguous()
         assert tuple(edge_index.shape) == (2, edges)
         with torch.cuda.device(self.device):
-            row_ptr = torch.empty(nodes + 1, dtype=torch.int32, device=self.device)
-            col = torch.empty(max(edges, 1), dtype=torch.int32, device=self.device)
-            typ = torch.empty(max(edges, 1), dtype=torch.uint8, device=self.device)
+            if out is not None and (out.nodes, out.edges) == (nodes, edges):
+                row_ptr, col, typ = out.row_ptr, out.col, out.typ
+            else:
+                row_ptr = torch.empty(nodes + 1, dtype=torch.int32, device=self.device)
+                col = torch.empty(max(edges, 1), dtype=torch.int32, device=self.device)
+                typ = torch.empty(max(edges, 1), dtype=torch.uint8, device=self.device)
             need = self._lib.gfy_csr_workspace_bytes(nodes, edges)
             scratch = self._scratch(need)
             native.check(self._lib.gfy_build_csr(

@@ -2,6 +2,7 @@
 // a synthetic 60k-node / 300k-edge shard, per-kernel device times.
 //   hipcc -O2 tools/gfy_bench.cpp -Iinclude -Lginfinity_amd/csrc -lgfy -o tools/gfy_bench
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -94,6 +95,29 @@ int main(int argc, char** argv) {
   CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
   CK(hipEventElapsedTime(&ms, e0, e1));
   printf("encode only: %.1f us/step\n", 1e3 * ms / steps);
+  for (int lanes = 2; lanes <= 4; ++lanes) {  // independent shards in flight on several streams
+    std::vector<gfy_encoder*> encs(lanes); std::vector<hipStream_t> ss(lanes);
+    std::vector<int32_t*> rp(lanes), cl(lanes); std::vector<uint8_t*> ty(lanes);
+    std::vector<void*> outs(lanes), wa(lanes), wb(lanes);
+    for (int q = 0; q < lanes; ++q) {
+      GK(gfy_encoder_create(pack.data(), bytes, GFY_F16, 0, &encs[q])); CK(hipStreamCreate(&ss[q]));
+      CK(hipMalloc(&rp[q], (N + 1) * 4)); CK(hipMalloc(&cl[q], E * 4)); CK(hipMalloc(&ty[q], E));
+      CK(hipMalloc(&outs[q], N * 128 * 2)); CK(hipMalloc(&wa[q], b1)); CK(hipMalloc(&wb[q], b2));
+    }
+    auto step = [&](int i) {
+      const int q = i % lanes;
+      GK(gfy_build_csr(dei, det, N, E, rp[q], cl[q], ty[q], wa[q], b1, ss[q]));
+      GK(gfy_encode(encs[q], dx, rp[q], cl[q], ty[q], N, E, nullptr, outs[q], GFY_F16, 1, wb[q], b2, ss[q]));
+    };
+    for (int i = 0; i < 24; ++i) step(i);
+    CK(hipDeviceSynchronize());
+    auto t0 = std::chrono::high_resolution_clock::now();
+    for (int i = 0; i < steps; ++i) step(i);
+    CK(hipDeviceSynchronize());
+    double us = std::chrono::duration<double, std::micro>(std::chrono::high_resolution_clock::now() - t0).count();
+    printf("%d streams: %.1f us/step -> %.1f M nodes/s\n", lanes, us / steps, N * steps / us);
+    for (int q = 0; q < lanes; ++q) gfy_encoder_destroy(encs[q]);
+  }
   GK(gfy_encoder_set_timing(enc, 1));
   double sum[16] = {0}; int cnt = 0;
   for (int i = 0; i < 50; ++i) {
