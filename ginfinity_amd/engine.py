@@ -182,7 +182,8 @@ class DeviceEncoder:
     def encode_arrays(self, node_features: np.ndarray, edge_index: np.ndarray,
                       edge_types: np.ndarray, node_roles: np.ndarray | None,
                       *, out_dtype: torch.dtype = torch.float16,
-                      normalise: bool = True) -> torch.Tensor:
+                      normalise: bool = True,
+                      out: torch.Tensor | None = None) -> torch.Tensor:
         """Host arrays of one shard slice → [core_nodes, 128] device tensor.
         Context nodes (role != 0) take part in message passing and are dropped
         in the head kernel's store (api.py:253-260)."""
@@ -201,4 +202,4 @@ class DeviceEncoder:
         et = torch.from_numpy(np.ascontiguousarray(edge_types)).to(self.device)
         csr = self.build_csr(ei, et, nodes)
         return self.encode(x, csr, out_rows=out_rows, n_out=n_out,
-                           out_dtype=out_dtype, normalise=normalise)
+                           out_dtype=out_dtype, normalise=normalise, out=out)
