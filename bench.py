@@ -59,6 +59,18 @@ def parse() -> argparse.Namespace:
     return parser.parse_args()
 
 
+def measured_traffic(kernel: str):
+    """HBM bytes per launch of ``kernel`` from the committed PMC passes
+    (profiles/r01b_traffic_pmc.json: rocprofv3 FETCH_SIZE/WRITE_SIZE, gfx950
+    half-count correction applied).  Counter passes cannot run inside this script;
+    None if the file is absent."""
+    path = ROOT / "profiles" / "r01b_traffic_pmc.json"
+    try:
+        return json.loads(path.read_text())["kernels"][kernel]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(seconds: float) -> dict:
     """Reference-equivalent CPU encode (same aten ops) on the same workload."""
     from ginfinity_amd import synthetic
@@ -164,7 +176,8 @@ def main() -> None:
         achieved = LAYER_BYTES / (layer_ms * 1e-3) / 1e9
         roofline = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": measured_traffic("k_gine_layer_f16"),
             "kernel": "k_gine_layer_f16", "kernel_ms": layer_ms,
             "algorithmic_bytes_per_launch": LAYER_BYTES,
             "mfma_tflops": LAYER_FLOPS / (layer_ms * 1e-3) / 1e12,
