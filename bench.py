@@ -98,7 +98,9 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
+    # under torch.distributed.run (RANK set) the process group is always created, so the
+    # RCCL path (barrier + MAX all-reduce) is the one exercised even at world size 1
+    distributed = "RANK" in os.environ
     if distributed:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)

@@ -333,3 +333,96 @@ def test_csr_large_shards(gpu_encoder, rouskin_shard):
         np.testing.assert_array_equal(csr.row_ptr.cpu().numpy(), row_ptr)
         np.testing.assert_array_equal(csr.col.cpu().numpy()[:e], col)
         np.testing.assert_array_equal(csr.typ.cpu().numpy()[:e], typ)
+
+
+# ---- fallback paths: hubs, oversized tiles, limits ----------------------------------------------
+
+def _hub_shard(seed, nodes=4000, hub_edges=3000, extra=9000):
+    """One record: a hub node with thousands of in-edges (its tile overflows the LDS
+    metadata slice -> CSR-from-memory path), a few nodes with in-degree 9..30
+    (beyond the in-flight slots) and self loops; every edge type 0..9."""
+    from ginfinity_amd import GraphShard, GraphSpec
+    rng = np.random.default_rng(seed)
+    spec = GraphSpec.bundled()
+    src = [rng.integers(0, nodes, hub_edges), rng.integers(0, nodes, extra)]
+    dst = [np.full(hub_edges, 777), rng.integers(0, nodes, extra)]
+    for node in (5, 64, 1999):
+        src.append(rng.integers(0, nodes, 25))
+        dst.append(np.full(25, node))
+    src.append(np.arange(100, 120))
+    dst.append(np.arange(100, 120))                         # self loops
+    edge_index = np.stack((np.concatenate(src), np.concatenate(dst))).astype(np.int32)
+    perm = rng.permutation(edge_index.shape[1])
+    edge_index = np.ascontiguousarray(edge_index[:, perm])
+    edge_types = rng.integers(0, 10, edge_index.shape[1]).astype(np.uint8)
+    return GraphShard(
+        identifiers=("hub",), sequences=("A" * nodes,), structures=("." * nodes,),
+        node_features=rng.standard_normal((nodes, 7)).astype(np.float32),
+        edge_index=edge_index, edge_types=edge_types,
+        node_ptr=np.array([0, nodes], np.int64),
+        edge_ptr=np.array([0, edge_index.shape[1]], np.int64), spec=spec,
+        residue_index=np.arange(nodes, dtype=np.int32),
+        node_roles=np.zeros(nodes, np.uint8))
+
+
+@pytest.mark.parametrize("full_precision", [False, True])
+def test_hub_graph_against_oracle(full_precision, checkpoint, oracle_weights):
+    """Hubs are not in any reference fixture; the oracle (pinned elsewhere) is the
+    checker.  fp16: accumulation of 3,000 fp16 messages in fp32 is order-sensitive
+    in the last bits, hence the looser bound on the hub row only."""
+    import torch
+    from oracle import gine_numpy as G
+    from ginfinity_amd.engine import DeviceEncoder
+    shard = _hub_shard(1)
+    engine = DeviceEncoder(checkpoint.weight_pack, full_precision=full_precision,
+                           device=torch.device("cuda"))
+    dtype = torch.float32 if full_precision else torch.float16
+    got = engine.encode_arrays(shard.node_features, shard.edge_index, shard.edge_types,
+                               None, out_dtype=dtype).cpu().numpy()
+    want = G.encode(oracle_weights, shard.node_features, shard.edge_index,
+                    shard.edge_types, full_precision=full_precision,
+                    embedding_dtype=np.float32 if full_precision else np.float16)
+    assert np.isfinite(got).all()
+    assert _maxabs(got, want) <= (2e-6 if full_precision else F16_TOL)
+    engine.close()
+
+
+def test_long_single_rna_and_many_tiny_graphs(gpu_encoder, oracle_weights):
+    from oracle import gine_numpy as G
+    from ginfinity_amd import GraphBuilder, RNA
+    rng = np.random.default_rng(3)
+    # the maximum length the input contract allows (4,096 nt), fully paired hairpin stack
+    seq = "".join(rng.choice(list("ACGU"), 4096))
+    struct = "(" * 2000 + "." * 96 + ")" * 2000
+    long_record = RNA("long", seq, struct)
+    tiny = [RNA(f"t{i}", "ACGU"[: 1 + i % 4], "." * (1 + i % 4)) for i in range(300)]
+    records = [long_record] + tiny
+    outputs = gpu_encoder.encode_many(records)
+    assert [o.shape[0] for o in outputs] == [r.length for r in records]
+    shard = GraphBuilder().build_shard(records)
+    want = G.encode(oracle_weights, shard.node_features, shard.edge_index, shard.edge_types)
+    assert _maxabs(np.concatenate(outputs), want) <= F16_TOL
+    # one record per micro-batch: the packing loop degenerates, results must not move
+    again = gpu_encoder.encode_many(records, max_batch_nodes=4096, max_batch_edges=20480)
+    np.testing.assert_array_equal(np.concatenate(again), np.concatenate(outputs))
+    with pytest.raises(ValueError, match="max_batch_nodes"):
+        gpu_encoder.encode_many(records, max_batch_nodes=4095)
+
+
+def test_abi_rejects_oversized_and_undersized_requests(gpu_encoder):
+    import torch
+    from ginfinity_amd import _native as native
+    engine = gpu_encoder._engine
+    lib = native.library()
+    tiny = torch.zeros(16, dtype=torch.uint8, device=engine.device)
+    x = torch.zeros((10, 7), dtype=torch.float32, device=engine.device)
+    rp = torch.zeros(11, dtype=torch.int32, device=engine.device)
+    out = torch.zeros((10, 128), dtype=torch.float16, device=engine.device)
+    status = lib.gfy_encode(engine._handle, x.data_ptr(), rp.data_ptr(), None, None, 10, 0,
+                            None, out.data_ptr(), native.GFY_F16, 1, tiny.data_ptr(),
+                            tiny.numel(), None)
+    assert status == native.GFY_ERR_WORKSPACE and b"workspace" in lib.gfy_last_error()
+    status = lib.gfy_encode(engine._handle, x.data_ptr(), rp.data_ptr(), None, None,
+                            (1 << 24) + 1, 0, None, out.data_ptr(), native.GFY_F16, 1,
+                            tiny.data_ptr(), 1 << 40, None)
+    assert status == native.GFY_ERR_UNSUPPORTED
