@@ -79,9 +79,10 @@ struct PairArgs {
 template <bool kDense>
 __global__ __launch_bounds__(kThreads, 2) void k_pairwise(const PairArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* tile = smem;                                            // 128 x 256 B
+  char* tile = smem;                                            // b-tile: 128 x 256 B
   float* s_l = reinterpret_cast<float*>(smem + kTileB * 256);   // [128]
   float* t_l = s_l + kTileB;                                     // [128]
+  char* atile = smem + kTileB * 256 + 2 * kTileB * 4;           // a-block: 128 x 256 B, resident
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int r = lane & 31, hq = lane >> 5;
@@ -97,16 +98,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_pairwise(const PairArgs p) {
     const int row = i >> 4, ch = i & 15;
     f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
     if (a0 + row < p.n) v = *reinterpret_cast<const f16x8*>(p.a + (a0 + row) * 128 + ch * 8);
-    *reinterpret_cast<f16x8*>(tile + off256(row, ch)) = v;
+    *reinterpret_cast<f16x8*>(atile + off256(row, ch)) = v;
   }
   __syncthreads();
-  f16x8 af[2][8];
+  // a-tile 0 fragments stay in registers, a-tile 1 is re-read from LDS per use: the
+  // registers go to the b-tile that is in flight (a whole tile ahead)
+  f16x8 af0[8];
 #pragma unroll
-  for (int at = 0; at < 2; ++at)
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
-      af[at][ks] = *reinterpret_cast<const f16x8*>(tile + off256(64 * wa + 32 * at + r, 2 * ks + hq));
-  __syncthreads();
+  for (int ks = 0; ks < 8; ++ks)
+    af0[ks] = *reinterpret_cast<const f16x8*>(atile + off256(64 * wa + r, 2 * ks + hq));
 
   float best[2];
   int bidx[2];
@@ -116,38 +116,38 @@ __global__ __launch_bounds__(kThreads, 2) void k_pairwise(const PairArgs p) {
     bidx[at] = 0x7fffffff;
   }
 
-  for (int64_t j0 = j_begin; j0 < j_end; j0 += kTileB) {
-    for (int i = t; i < kTileB * 16; i += kThreads) {
+  // b-tiles are requested one iteration ahead (registers), written to LDS at the top
+  // of the iteration that consumes them: the round trip hides under the MFMAs
+  f16x8 pre[8];
+  float pre_s = 0.f, pre_t = __builtin_inff();
+  auto request = [&](int64_t j0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = t + q * kThreads;
       const int row = i >> 4, ch = i & 15;
-      f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (j0 + row < p.m) v = *reinterpret_cast<const f16x8*>(p.b + (j0 + row) * 128 + ch * 8);
-      *reinterpret_cast<f16x8*>(tile + off256(row, ch)) = v;
+      pre[q] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (j0 + row < p.m) pre[q] = *reinterpret_cast<const f16x8*>(p.b + (j0 + row) * 128 + ch * 8);
     }
     if (t < kTileB) {
       const bool ok = j0 + t < p.m;
-      s_l[t] = ok ? p.s[j0 + t] : 0.f;
-      t_l[t] = ok ? p.t[j0 + t] : __builtin_inff();   // key = +inf: never wins
+      pre_s = ok ? p.s[j0 + t] : 0.f;
+      pre_t = ok ? p.t[j0 + t] : __builtin_inff();   // key = +inf: never wins
+    }
+  };
+  if (j_begin < j_end) request(j_begin);
+
+  for (int64_t j0 = j_begin; j0 < j_end; j0 += kTileB) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = t + q * kThreads;
+      *reinterpret_cast<f16x8*>(tile + off256(i >> 4, i & 15)) = pre[q];
+    }
+    if (t < kTileB) {
+      s_l[t] = pre_s;
+      t_l[t] = pre_t;
     }
     __syncthreads();
-
-    f32x16 acc[2][2];  // [b-tile][a-tile]
-#pragma unroll
-    for (int bt = 0; bt < 2; ++bt)
-#pragma unroll
-      for (int at = 0; at < 2; ++at)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[bt][at][q] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-#pragma unroll
-      for (int bt = 0; bt < 2; ++bt) {
-        const f16x8 bf = *reinterpret_cast<const f16x8*>(
-            tile + off256(64 * wb + 32 * bt + r, 2 * ks + hq));
-#pragma unroll
-        for (int at = 0; at < 2; ++at)
-          acc[bt][at] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf, af[at][ks], acc[bt][at], 0, 0, 0);
-      }
-    }
+    if (j0 + kTileB < j_end) request(j0 + kTileB);
 
     // does this tile contain an excluded (i, i + offset) pair of this block?
     const int64_t ex_lo = a0 + p.exclude_offset, ex_hi = ex_lo + kBlockA;
@@ -155,6 +155,22 @@ __global__ __launch_bounds__(kThreads, 2) void k_pairwise(const PairArgs p) {
 
 #pragma unroll
     for (int bt = 0; bt < 2; ++bt) {
+      // one 32-row b-tile at a time: 2 accumulators live (VGPR budget: the a-block
+      // fragments and the next b-tile in flight take 96 registers)
+      f32x16 accs[2];
+#pragma unroll
+      for (int at = 0; at < 2; ++at)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) accs[at][q] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const f16x8 bf = *reinterpret_cast<const f16x8*>(
+            tile + off256(64 * wb + 32 * bt + r, 2 * ks + hq));
+        const f16x8 af1 = *reinterpret_cast<const f16x8*>(
+            atile + off256(64 * wa + 32 + r, 2 * ks + hq));
+        accs[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf, af0[ks], accs[0], 0, 0, 0);
+        accs[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf, af1, accs[1], 0, 0, 0);
+      }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int jl = 64 * wb + 32 * bt + 8 * g + 4 * hq;  // 4 consecutive b-rows
@@ -168,7 +184,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_pairwise(const PairArgs p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const int64_t j = j0 + jl + i;
-              const float key = __builtin_fmaf(acc[bt][at][4 * g + i], sv[i], tv[i]);
+              const float key = __builtin_fmaf(accs[at][4 * g + i], sv[i], tv[i]);
               if (ai < p.n && j < p.m) {
                 float val;
                 if (p.metric == GFY_L2) {
@@ -183,7 +199,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_pairwise(const PairArgs p) {
           } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              float key = __builtin_fmaf(acc[bt][at][4 * g + i], sv[i], tv[i]);
+              float key = __builtin_fmaf(accs[at][4 * g + i], sv[i], tv[i]);
               const int j = (int)(j0 + jl + i);
               if (may_exclude && (int64_t)j == ai + p.exclude_offset) key = __builtin_inff();
               if (key < best[at]) {   // ascending j inside a lane: strict < keeps the lowest index
@@ -293,7 +309,7 @@ PairWorkspace carve(void* base, int64_t n, int64_t m) {
   return w;
 }
 
-constexpr int kPairLds = kTileB * 256 + 2 * kTileB * 4;
+constexpr int kPairLds = kTileB * 256 + 2 * kTileB * 4 + kBlockA * 256;   // b-tile, (s,t), a-block
 
 }  // namespace
 
@@ -325,6 +341,14 @@ int launch_pairwise_nearest(const void* a, int64_t n, const void* b, int64_t m,
   p.chunk_rows = w.chunk_rows;
   p.part_val = w.part_val;
   p.part_idx = w.part_idx;
+  static bool lds_opt_in = false;
+  if (!lds_opt_in) {
+    GFY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kPairLds));
+    GFY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kPairLds));
+    lds_opt_in = true;
+  }
   k_pairwise<false><<<w.blocks_a * w.chunks, kThreads, kPairLds, s>>>(p);
   k_nearest_finish<<<(int)((n + 255) / 256), 256, 0, s>>>(
       w.part_val, w.part_idx, w.a_term, n, w.chunks, metric, best_val, best_idx);
@@ -359,6 +383,8 @@ int launch_pairwise_dense(const void* a, int64_t n, const void* b, int64_t m,
   p.chunks = 1;
   p.chunk_rows = (m + kTileB - 1) / kTileB * kTileB;
   p.dense = out;
+  GFY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kPairLds));
   k_pairwise<true><<<p.blocks_a, kThreads, kPairLds, s>>>(p);
   GFY_CHECK_HIP(hipGetLastError());
   return GFY_OK;
