@@ -148,28 +148,35 @@ struct TileWalk {
 __global__ __launch_bounds__(256) void k_input_linear_f16(
     const float* __restrict__ x, const f16* __restrict__ w_in /*[8][16][8] packed*/,
     const f16* __restrict__ b_in, f16* __restrict__ h, int n) {
-  // 16 lanes per node, 8 channels per lane.  w_in is stored [c][chunk][k]
-  // (channel = 8*chunk + c) so that for a fixed c the 16 lanes of a node read
-  // 256 contiguous bytes: a per-channel-row layout makes every lane hit its
-  // own 128-B line and costs ~64 cycles per load instruction (measured).
-  const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t node = item >> 4;
-  const int chunk = (int)(item & 15);
-  if (node >= n) return;
-  float xv[kInDim];
+  // 16 lanes per node, 8 channels per lane, grid-stride over node groups.  The 2-KB
+  // weight matrix is staged in LDS once per workgroup, laid out [c][chunk][k]
+  // (channel = 8*chunk + c) so a wave's read of one c is 256 contiguous bytes; reading
+  // it per-channel-row from memory made every lane hit its own 128-B line (~64 cycles
+  // per load instruction, tools/probe.hip).
+  __shared__ f16x8 ws[128];
+  __shared__ f16x8 bs[16];
+  if (threadIdx.x < 128) ws[threadIdx.x] = reinterpret_cast<const f16x8*>(w_in)[threadIdx.x];
+  if (threadIdx.x < 16) bs[threadIdx.x] = reinterpret_cast<const f16x8*>(b_in)[threadIdx.x];
+  __syncthreads();
+  const int chunk = threadIdx.x & 15;
+  const f16x8 bias = bs[chunk];
+  const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 4);
+  for (int64_t node = (int64_t)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4); node < n;
+       node += stride) {
+    float xv[kInDim];
 #pragma unroll
-  for (int k = 0; k < kInDim; ++k) xv[k] = (float)(f16)x[node * kInDim + k];
-  const f16x8 bias = *reinterpret_cast<const f16x8*>(b_in + chunk * 8);
-  f16x8 out;
+    for (int k = 0; k < kInDim; ++k) xv[k] = (float)(f16)x[node * kInDim + k];
+    f16x8 out;
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const f16x8 w = *reinterpret_cast<const f16x8*>(w_in + (c * 16 + chunk) * 8);
-    float acc = 0.f;
+    for (int c = 0; c < 8; ++c) {
+      const f16x8 w = ws[c * 16 + chunk];
+      float acc = 0.f;
 #pragma unroll
-    for (int k = 0; k < kInDim; ++k) acc = __builtin_fmaf(xv[k], (float)w[k], acc);
-    out[c] = (f16)(acc + (float)bias[c]);
+      for (int k = 0; k < kInDim; ++k) acc = __builtin_fmaf(xv[k], (float)w[k], acc);
+      out[c] = (f16)(acc + (float)bias[c]);
+    }
+    *reinterpret_cast<f16x8*>(h + node * kHidden + chunk * 8) = out;
   }
-  *reinterpret_cast<f16x8*>(h + node * kHidden + chunk * 8) = out;
 }
 
 // ---------------------------------------------------------------------------------
@@ -760,8 +767,11 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
 
   const int64_t items = n * 16;
   enc->mark(s, 0);
-  k_input_linear_f16<<<(int)((items + 255) / 256), 256, 0, s>>>(
-      x, enc->f16.w_in, enc->f16.b_in, ha, (int)n);
+  {
+    const int64_t blocks = (items + 255) / 256;
+    k_input_linear_f16<<<(int)(blocks > 2048 ? 2048 : blocks), 256, 0, s>>>(
+        x, enc->f16.w_in, enc->f16.b_in, ha, (int)n);
+  }
   enc->mark(s, 1);
   const int stop = tap_stage >= 0 ? tap_stage : enc->layers;
   // GFY_LAYER_KERNEL=ws selects the experimental wave-specialised kernel
