@@ -741,9 +741,12 @@ extern "C" int gfy_debug_stamps(unsigned long long* host /*[256][8]*/, int reset
 }
 #endif
 
-size_t encode_f16_workspace_bytes(int64_t n, int64_t /*e*/) {
-  return 2 * align_up((size_t)n * kHidden * sizeof(f16), 256);
+// two hidden-state buffers, each padded with spare rows behind the last node (the
+// wave-specialised kernel stores unconditionally; rows that do not exist land there)
+static size_t h_buffer_bytes(int64_t n) {
+  return align_up((size_t)(n + 2 * kTile) * kHidden * sizeof(f16), 256);
 }
+size_t encode_f16_workspace_bytes(int64_t n, int64_t /*e*/) { return 2 * h_buffer_bytes(n); }
 
 int launch_encode_f16(const gfy_encoder* enc, const float* x,
                       const int32_t* row_ptr, const int32_t* col,
@@ -797,12 +800,16 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
     lds_opt_in = true;
   }
   for (int l = 0; l < stop; ++l) {
+    // the ws kernel prefetches unconditionally: give it readable col/typ even for E = 0
+    const int32_t* ws_col = e > 0 ? col : row_ptr;
+    const uint8_t* ws_typ = e > 0 ? typ : reinterpret_cast<const uint8_t*>(row_ptr);
+    const int ws_edges = e > 0 ? (int)e : 1;
     if (use_ws && enc->residual)
       k_gine_layer_ws<true><<<ws_grid, kThreads, kWsBytes, s>>>(
-          enc->f16.layer[l], ha, hb, row_ptr, col, typ, (int)n, ws_tiles);
+          enc->f16.layer[l], ha, hb, row_ptr, ws_col, ws_typ, (int)n, ws_tiles, ws_edges);
     else if (use_ws)
       k_gine_layer_ws<false><<<ws_grid, kThreads, kWsBytes, s>>>(
-          enc->f16.layer[l], ha, hb, row_ptr, col, typ, (int)n, ws_tiles);
+          enc->f16.layer[l], ha, hb, row_ptr, ws_col, ws_typ, (int)n, ws_tiles, ws_edges);
     else if (enc->residual)
       k_gine_layer_f16<true><<<grid, kThreads, kLdsLayerBytes, s>>>(
           enc->f16.layer[l], ha, hb, row_ptr, col, typ, (int)n, num_tiles);
