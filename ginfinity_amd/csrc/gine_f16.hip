@@ -44,7 +44,7 @@ constexpr int kLdsZW = 0;                       // 64 x 256 B  z, later w
 constexpr int kLdsV = kLdsZW + kTile * 256;     // 64 x 512 B  v
 constexpr int kLdsTable = kLdsV + kTile * 512;  // 16 x 128 f16 edge table
 constexpr int kLdsB0 = kLdsTable + kMaxEdgeTypes * kHidden * 2;
-constexpr int kLdsAlpha = kLdsB0 + kMlp * 2;
+constexpr int kLdsAlpha = kLdsB0 + kMlp * 4;    // b0 is kept widened to fp32
 constexpr int kLdsShift = kLdsAlpha + kMlp * 4;
 constexpr int kLdsB1 = kLdsShift + kMlp * 4;
 // CSR slice of a tile, double-buffered (tile t is consumed while t+1 is fetched)
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_gine_layer_f16(
   char* const zw = smem + kLdsZW;
   char* const vt = smem + kLdsV;
   f16* const table = reinterpret_cast<f16*>(smem + kLdsTable);
-  f16* const b0s = reinterpret_cast<f16*>(smem + kLdsB0);
+  float* const b0s = reinterpret_cast<float*>(smem + kLdsB0);
   float* const alphas = reinterpret_cast<float*>(smem + kLdsAlpha);
   float* const shifts = reinterpret_cast<float*>(smem + kLdsShift);
   f16* const b1s = reinterpret_cast<f16*>(smem + kLdsB1);
@@ -246,8 +246,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_gine_layer_f16(
   for (int i = t; i < kMaxEdgeTypes * kHidden / 8; i += kThreads)
     reinterpret_cast<f16x8*>(table)[i] =
         reinterpret_cast<const f16x8*>(p.edge_table)[i];
-  if (t < kMlp / 8)
-    reinterpret_cast<f16x8*>(b0s)[t] = reinterpret_cast<const f16x8*>(p.b0)[t];
+  if (t < kMlp) b0s[t] = (float)p.b0[t];
   if (t < kMlp / 4) {
     reinterpret_cast<f32x4*>(alphas)[t] = reinterpret_cast<const f32x4*>(p.bn_alpha)[t];
     reinterpret_cast<f32x4*>(shifts)[t] = reinterpret_cast<const f32x4*>(p.bn_shift)[t];
@@ -419,22 +418,25 @@ __global__ __launch_bounds__(kThreads, 2) void k_gine_layer_f16(
       }
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) acc1 = mfma(w0f[ks], z1f[ks], acc1);
+      // epilogue on 4-wide vectors so that hipcc emits the packed forms
+      // (v_pk_add_f32, v_cvt_pk_f16_f32, v_pk_fma_f32, v_pk_max_f16): the scalar
+      // spelling cost ~12 VALU instructions per value and made this phase
+      // issue-bound (profiles/README.md)
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int c0 = wave * 32 + 8 * g + 4 * hq;  // 4 consecutive channels
-          const f16x4 b0v = *reinterpret_cast<const f16x4*>(b0s + c0);
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(b0s + c0);
           const f32x4 al = *reinterpret_cast<const f32x4*>(alphas + c0);
           const f32x4 sh = *reinterpret_cast<const f32x4*>(shifts + c0);
-          f16x4 vv;
+          f32x4 a4;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float a = half == 0 ? acc0[4 * g + i] : acc1[4 * g + i];
-            const f16 u = (f16)(a + (float)b0v[i]);
-            const f16 y = (f16)__builtin_fmaf((float)u, al[i], sh[i]);
-            vv[i] = y > (f16)0 ? y : (f16)0;
-          }
+          for (int i = 0; i < 4; ++i) a4[i] = half == 0 ? acc0[4 * g + i] : acc1[4 * g + i];
+          const f16x4 u4 = __builtin_convertvector(a4 + b4, f16x4);               // R(acc + b0)
+          const f32x4 y4 = __builtin_elementwise_fma(__builtin_convertvector(u4, f32x4), al, sh);
+          const f16x4 zero4 = {0, 0, 0, 0};
+          const f16x4 vv = __builtin_elementwise_max(__builtin_convertvector(y4, f16x4), zero4);
           *reinterpret_cast<f16x4*>(vt + off512(32 * half + r, c0 >> 3) + hq * 8) = vv;
         }
       }
@@ -455,10 +457,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_gine_layer_f16(
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int c0 = ct * 32 + 8 * g + 4 * hq;
-        const f16x4 b1v = *reinterpret_cast<const f16x4*>(b1s + c0);
-        f16x4 wv;
+        const f32x4 b4 = __builtin_convertvector(*reinterpret_cast<const f16x4*>(b1s + c0), f32x4);
+        f32x4 a4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wv[i] = (f16)(acc[4 * g + i] + (float)b1v[i]);
+        for (int i = 0; i < 4; ++i) a4[i] = acc[4 * g + i];
+        const f16x4 wv = __builtin_convertvector(a4 + b4, f16x4);
         *reinterpret_cast<f16x4*>(zw + off256(32 * nt + r, c0 >> 3) + hq * 8) = wv;
       }
     }
