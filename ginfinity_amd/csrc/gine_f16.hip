@@ -121,7 +121,8 @@ __device__ __forceinline__ float row16_sum32(float v) {
 // Diagnostic build only (python -m ginfinity_amd.build --stamps): per-phase
 // shader-clock totals of the layer kernel, one row per workgroup.  Never compiled
 // into libgfy.so proper.
-__device__ unsigned long long g_stamps[256][8];
+__device__ unsigned long long g_stamps[256][16];
+__device__ unsigned long long g_real[512][2];   // last launch: 100 MHz begin / end per workgroup
 #define STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
 #else
 #define STAMP(var)
@@ -535,6 +536,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_gine_layer_f16(
 }
 
 #include "gine_layer_ws.inc"
+#include "gine_layer_dma.inc"
 
 // ---------------------------------------------------------------------------------
 // head + normalise
@@ -732,11 +734,16 @@ int persistent_grid(int num_tiles) {
 }  // namespace
 
 #ifdef GFY_STAMPS
-extern "C" int gfy_debug_stamps(unsigned long long* host /*[256][8]*/, int reset) {
+extern "C" int gfy_debug_real(unsigned long long* host /*[512][2]*/) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_real), sizeof(g_real)) == hipSuccess
+             ? GFY_OK
+             : GFY_ERR_HIP;
+}
+extern "C" int gfy_debug_stamps(unsigned long long* host /*[256][16]*/, int reset) {
   if (host && hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) != hipSuccess)
     return GFY_ERR_HIP;
   if (reset) {
-    static unsigned long long zeros[256][8] = {};
+    static unsigned long long zeros[256][16] = {};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zeros, sizeof(zeros)) != hipSuccess)
       return GFY_ERR_HIP;
   }
@@ -770,6 +777,10 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
   const int grid = persistent_grid(num_tiles);
   const int ws_tiles = (int)((n + kWt - 1) / kWt);
   const int ws_grid = persistent_grid(ws_tiles);
+  const int dma_tiles = (int)((n + kT2 - 1) / kT2);
+  int dma_grid = dma_tiles < 512 ? dma_tiles : 512;   // two 256-thread workgroups per CU
+  dma_grid = (dma_grid + 7) & ~7;
+  if (const char* g = getenv("GFY_DMA_GRID")) dma_grid = atoi(g);   // diagnostic
 
   const int64_t items = n * 16;
   enc->mark(s, 0);
@@ -786,6 +797,12 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
     const char* v = getenv("GFY_LAYER_KERNEL");
     return v && v[0] == 'w';
   }();
+  // default: the LDS-DMA kernel (gine_layer_dma.inc); GFY_LAYER_KERNEL=v1 / ws select the
+  // earlier kernels for A/B runs
+  static const bool use_dma = [] {
+    const char* v = getenv("GFY_LAYER_KERNEL");
+    return !v || v[0] == 'd';
+  }();
   static bool lds_opt_in = false;   // > 64 KB of dynamic LDS needs an explicit opt-in
   if (!lds_opt_in) {
     GFY_CHECK_HIP(hipFuncSetAttribute(
@@ -800,6 +817,12 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
     GFY_CHECK_HIP(hipFuncSetAttribute(
         reinterpret_cast<const void*>(&k_gine_layer_f16<false>),
         hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLayerBytes));
+    GFY_CHECK_HIP(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&k_gine_layer_dma<true>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, k2Bytes));
+    GFY_CHECK_HIP(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&k_gine_layer_dma<false>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, k2Bytes));
     lds_opt_in = true;
   }
   for (int l = 0; l < stop; ++l) {
@@ -807,7 +830,13 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
     const int32_t* ws_col = e > 0 ? col : row_ptr;
     const uint8_t* ws_typ = e > 0 ? typ : reinterpret_cast<const uint8_t*>(row_ptr);
     const int ws_edges = e > 0 ? (int)e : 1;
-    if (use_ws && enc->residual)
+    if (use_dma && enc->residual)
+      k_gine_layer_dma<true><<<dma_grid, kThreads2, k2Bytes, s>>>(
+          enc->f16.layer[l], ha, hb, row_ptr, col, typ, (int)n, dma_tiles);
+    else if (use_dma)
+      k_gine_layer_dma<false><<<dma_grid, kThreads2, k2Bytes, s>>>(
+          enc->f16.layer[l], ha, hb, row_ptr, col, typ, (int)n, dma_tiles);
+    else if (use_ws && enc->residual)
       k_gine_layer_ws<true><<<ws_grid, kThreads, kWsBytes, s>>>(
           enc->f16.layer[l], ha, hb, row_ptr, ws_col, ws_typ, (int)n, ws_tiles, ws_edges);
     else if (use_ws)

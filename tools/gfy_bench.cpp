@@ -11,6 +11,7 @@
 #include "gfy.h"
 #ifdef GFY_STAMPS
 extern "C" int gfy_debug_stamps(unsigned long long*, int);
+extern "C" int gfy_debug_real(unsigned long long*);
 #endif
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
@@ -130,15 +131,15 @@ int main(int argc, char** argv) {
   printf("\n");
 #ifdef GFY_STAMPS
   {
-    static unsigned long long st[256][8];
+    static unsigned long long st[256][16];
     gfy_debug_stamps(nullptr, 1);
     const int reps = 20;
     for (int i = 0; i < reps; ++i)
       GK(gfy_encode(enc, dx, drp, dcol, dtyp, N, E, nullptr, dout, GFY_F16, 1, ws2, b2, s));
     CK(hipStreamSynchronize(s));
     gfy_debug_stamps(&st[0][0], 0);
-    double sum[8] = {0};
-    for (int b = 0; b < 256; ++b) for (int k = 0; k < 8; ++k) sum[k] += (double)st[b][k];
+    double sum[16] = {0};
+    for (int b = 0; b < 256; ++b) for (int k = 0; k < 16; ++k) sum[k] += (double)st[b][k];
     {
       const double launches = reps * 4.0 * 256;   // 4 layers, 256 workgroups
       double tmax = 0, tmin = 1e30;
@@ -148,6 +149,26 @@ int main(int argc, char** argv) {
     }
     printf("ws stamps per step: matrix GEMM1 %.0f waitB1 %.0f GEMM2 %.0f waitB2 %.0f | vector first-half %.0f second-half %.0f (steps %.0f)\n",
            sum[0] / sum[5], sum[1] / sum[5], sum[2] / sum[5], sum[3] / sum[5], sum[4] / sum[5], sum[6] / sum[5], sum[5]);
+    {
+      static unsigned long long real[512][2];
+      gfy_debug_real(&real[0][0]);
+      unsigned long long b0 = ~0ull, b1 = 0, e0 = ~0ull, e1 = 0;
+      int used = 0;
+      for (int b = 0; b < 512; ++b) {
+        if (!real[b][1]) continue;
+        ++used;
+        b0 = real[b][0] < b0 ? real[b][0] : b0; b1 = real[b][0] > b1 ? real[b][0] : b1;
+        e0 = real[b][1] < e0 ? real[b][1] : e0; e1 = real[b][1] > e1 ? real[b][1] : e1;
+      }
+      if (used)
+        printf("last layer launch, real time (100 MHz): %d workgroups, first start -> last start %.2f us, "
+               "first end %.2f us, last end %.2f us after the first start\n",
+               used, (b1 - b0) / 100.0, (e0 - b0) / 100.0, (e1 - b0) / 100.0);
+    }
+    if (sum[8] > 0)
+      printf("  B split: z reads + MFMA issue %.0f | look-ahead issue %.0f | epilogue+barrier %.0f ;  C split: MFMA issue %.0f | epilogue %.0f | - %.0f | barrier %.0f ;  D split: final dma wait %.0f | LN+store+barrier %.0f\n",
+             sum[8] / sum[5], sum[9] / sum[5], sum[10] / sum[5], sum[11] / sum[5], sum[12] / sum[5],
+             sum[13] / sum[5], sum[14] / sum[5], sum[15] / sum[5], (sum[4] - sum[15]) / sum[5]);
     const double tiles = sum[5];
     printf("layer-kernel phases, shader cycles per tile (mean over %d tiles): gather %.0f | A->B barrier wait %.0f | GEMM1 %.0f | GEMM2 %.0f | LN+store %.0f | total %.0f\n",
            (int)tiles, sum[0] / tiles, sum[1] / tiles, sum[2] / tiles, sum[3] / tiles, sum[4] / tiles,
