@@ -537,6 +537,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_gine_layer_f16(
 
 #include "gine_layer_ws.inc"
 #include "gine_layer_dma.inc"
+#include "gine_layer_w8.inc"
 
 // ---------------------------------------------------------------------------------
 // head + normalise
@@ -799,6 +800,10 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
   }();
   // default: the LDS-DMA kernel (gine_layer_dma.inc); GFY_LAYER_KERNEL=v1 / ws select the
   // earlier kernels for A/B runs
+  static const bool use_w8 = [] {
+    const char* v = getenv("GFY_LAYER_KERNEL");
+    return v && v[0] == '8';
+  }();
   static const bool use_dma = [] {
     const char* v = getenv("GFY_LAYER_KERNEL");
     return !v || v[0] == 'd';
@@ -823,6 +828,12 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
     GFY_CHECK_HIP(hipFuncSetAttribute(
         reinterpret_cast<const void*>(&k_gine_layer_dma<false>),
         hipFuncAttributeMaxDynamicSharedMemorySize, k2Bytes));
+    GFY_CHECK_HIP(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&k_gine_layer_w8<true>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, k2Bytes));
+    GFY_CHECK_HIP(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&k_gine_layer_w8<false>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, k2Bytes));
     lds_opt_in = true;
   }
   for (int l = 0; l < stop; ++l) {
@@ -830,7 +841,13 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
     const int32_t* ws_col = e > 0 ? col : row_ptr;
     const uint8_t* ws_typ = e > 0 ? typ : reinterpret_cast<const uint8_t*>(row_ptr);
     const int ws_edges = e > 0 ? (int)e : 1;
-    if (use_dma && enc->residual)
+    if (use_w8 && enc->residual)
+      k_gine_layer_w8<true><<<dma_grid, kThreads3, k2Bytes, s>>>(
+          enc->f16.layer[l], ha, hb, row_ptr, col, typ, (int)n, dma_tiles);
+    else if (use_w8)
+      k_gine_layer_w8<false><<<dma_grid, kThreads3, k2Bytes, s>>>(
+          enc->f16.layer[l], ha, hb, row_ptr, col, typ, (int)n, dma_tiles);
+    else if (use_dma && enc->residual)
       k_gine_layer_dma<true><<<dma_grid, kThreads2, k2Bytes, s>>>(
           enc->f16.layer[l], ha, hb, row_ptr, col, typ, (int)n, dma_tiles);
     else if (use_dma)
