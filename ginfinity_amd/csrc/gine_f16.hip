@@ -535,9 +535,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_gine_layer_f16(
 #endif
 }
 
-#include "gine_layer_ws.inc"
 #include "gine_layer_dma.inc"
-#include "gine_layer_w8.inc"
 
 // ---------------------------------------------------------------------------------
 // head + normalise
@@ -757,7 +755,13 @@ extern "C" int gfy_debug_stamps(unsigned long long* host /*[256][16]*/, int rese
 static size_t h_buffer_bytes(int64_t n) {
   return align_up((size_t)(n + 2 * kTile) * kHidden * sizeof(f16), 256);
 }
-size_t encode_f16_workspace_bytes(int64_t n, int64_t /*e*/) { return 2 * h_buffer_bytes(n); }
+// ... plus one plan per 32-node tile (gine_layer_dma.inc)
+static size_t plan_bytes(int64_t n) {
+  return align_up((size_t)((n + kT2 - 1) / kT2) * kPlanBytes, 256);
+}
+size_t encode_f16_workspace_bytes(int64_t n, int64_t /*e*/) {
+  return 2 * h_buffer_bytes(n) + plan_bytes(n);
+}
 
 int launch_encode_f16(const gfy_encoder* enc, const float* x,
                       const int32_t* row_ptr, const int32_t* col,
@@ -773,18 +777,25 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
               "gfy_encode: fp16 path addresses rows with 32-bit byte offsets; "
               "split micro-batches above 16,777,216 nodes (got %lld)", (long long)n);
   f16* ha = (f16*)ws;
-  f16* hb = (f16*)((char*)ws + need / 2);
+  f16* hb = (f16*)((char*)ws + h_buffer_bytes(n));
+  char* plans = (char*)ws + 2 * h_buffer_bytes(n);
   const int num_tiles = (int)((n + kTile - 1) / kTile);
   const int grid = persistent_grid(num_tiles);
-  const int ws_tiles = (int)((n + kWt - 1) / kWt);
-  const int ws_grid = persistent_grid(ws_tiles);
   const int dma_tiles = (int)((n + kT2 - 1) / kT2);
   int dma_grid = dma_tiles < 512 ? dma_tiles : 512;   // two 256-thread workgroups per CU
   dma_grid = (dma_grid + 7) & ~7;
   if (const char* g = getenv("GFY_DMA_GRID")) dma_grid = atoi(g);   // diagnostic
+  // default: the LDS-DMA kernel (gine_layer_dma.inc); GFY_LAYER_KERNEL=v1 selects the
+  // first-generation kernel for A/B runs
+  static const bool use_dma = [] {
+    const char* v = getenv("GFY_LAYER_KERNEL");
+    return !v || v[0] == 'd';
+  }();
 
   const int64_t items = n * 16;
   enc->mark(s, 0);
+  if (use_dma && dma_tiles > 0 && tap_stage != 0)   // tile plans: once for all layers
+    k_tile_plan<<<dma_tiles, kThreads2, 0, s>>>(row_ptr, col, typ, (int)n, plans);
   {
     const int64_t blocks = (items + 255) / 256;
     k_input_linear_f16<<<(int)(blocks > 2048 ? 2048 : blocks), 256, 0, s>>>(
@@ -792,30 +803,8 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
   }
   enc->mark(s, 1);
   const int stop = tap_stage >= 0 ? tap_stage : enc->layers;
-  // GFY_LAYER_KERNEL=ws selects the experimental wave-specialised kernel
-  // (gine_layer_ws.inc: correct, currently slower — kept for A/B runs)
-  static const bool use_ws = [] {
-    const char* v = getenv("GFY_LAYER_KERNEL");
-    return v && v[0] == 'w';
-  }();
-  // default: the LDS-DMA kernel (gine_layer_dma.inc); GFY_LAYER_KERNEL=v1 / ws select the
-  // earlier kernels for A/B runs
-  static const bool use_w8 = [] {
-    const char* v = getenv("GFY_LAYER_KERNEL");
-    return v && v[0] == '8';
-  }();
-  static const bool use_dma = [] {
-    const char* v = getenv("GFY_LAYER_KERNEL");
-    return !v || v[0] == 'd';
-  }();
   static bool lds_opt_in = false;   // > 64 KB of dynamic LDS needs an explicit opt-in
   if (!lds_opt_in) {
-    GFY_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&k_gine_layer_ws<true>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, kWsBytes));
-    GFY_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&k_gine_layer_ws<false>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, kWsBytes));
     GFY_CHECK_HIP(hipFuncSetAttribute(
         reinterpret_cast<const void*>(&k_gine_layer_f16<true>),
         hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLayerBytes));
@@ -828,37 +817,15 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
     GFY_CHECK_HIP(hipFuncSetAttribute(
         reinterpret_cast<const void*>(&k_gine_layer_dma<false>),
         hipFuncAttributeMaxDynamicSharedMemorySize, k2Bytes));
-    GFY_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&k_gine_layer_w8<true>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, k2Bytes));
-    GFY_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&k_gine_layer_w8<false>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, k2Bytes));
     lds_opt_in = true;
   }
   for (int l = 0; l < stop; ++l) {
-    // the ws kernel prefetches unconditionally: give it readable col/typ even for E = 0
-    const int32_t* ws_col = e > 0 ? col : row_ptr;
-    const uint8_t* ws_typ = e > 0 ? typ : reinterpret_cast<const uint8_t*>(row_ptr);
-    const int ws_edges = e > 0 ? (int)e : 1;
-    if (use_w8 && enc->residual)
-      k_gine_layer_w8<true><<<dma_grid, kThreads3, k2Bytes, s>>>(
-          enc->f16.layer[l], ha, hb, row_ptr, col, typ, (int)n, dma_tiles);
-    else if (use_w8)
-      k_gine_layer_w8<false><<<dma_grid, kThreads3, k2Bytes, s>>>(
-          enc->f16.layer[l], ha, hb, row_ptr, col, typ, (int)n, dma_tiles);
-    else if (use_dma && enc->residual)
+    if (use_dma && enc->residual)
       k_gine_layer_dma<true><<<dma_grid, kThreads2, k2Bytes, s>>>(
-          enc->f16.layer[l], ha, hb, row_ptr, col, typ, (int)n, dma_tiles);
+          enc->f16.layer[l], ha, hb, row_ptr, col, typ, plans, (int)n, dma_tiles);
     else if (use_dma)
       k_gine_layer_dma<false><<<dma_grid, kThreads2, k2Bytes, s>>>(
-          enc->f16.layer[l], ha, hb, row_ptr, col, typ, (int)n, dma_tiles);
-    else if (use_ws && enc->residual)
-      k_gine_layer_ws<true><<<ws_grid, kThreads, kWsBytes, s>>>(
-          enc->f16.layer[l], ha, hb, row_ptr, ws_col, ws_typ, (int)n, ws_tiles, ws_edges);
-    else if (use_ws)
-      k_gine_layer_ws<false><<<ws_grid, kThreads, kWsBytes, s>>>(
-          enc->f16.layer[l], ha, hb, row_ptr, ws_col, ws_typ, (int)n, ws_tiles, ws_edges);
+          enc->f16.layer[l], ha, hb, row_ptr, col, typ, plans, (int)n, dma_tiles);
     else if (enc->residual)
       k_gine_layer_f16<true><<<grid, kThreads, kLdsLayerBytes, s>>>(
           enc->f16.layer[l], ha, hb, row_ptr, col, typ, (int)n, num_tiles);
