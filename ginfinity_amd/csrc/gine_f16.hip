@@ -146,10 +146,10 @@ struct TileWalk {
 // ---------------------------------------------------------------------------------
 // input Linear: h0 = R(R(x) . Win^T + b)            (_model.py:67, api.py:237-238)
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_input_linear_f16(
+__device__ __forceinline__ void input_linear_block(
     const float* __restrict__ x, const f16* __restrict__ w_in /*[8][16][8] packed*/,
-    const f16* __restrict__ b_in, f16* __restrict__ h, int n) {
-  // 16 lanes per node, 8 channels per lane, grid-stride over node groups.  The 2-KB
+    const f16* __restrict__ b_in, f16* __restrict__ h, int n, int block, int blocks) {
+  // 16 lanes per node, 8 channels per lane, block-stride over node groups.  The 2-KB
   // weight matrix is staged in LDS once per workgroup, laid out [c][chunk][k]
   // (channel = 8*chunk + c) so a wave's read of one c is 256 contiguous bytes; reading
   // it per-channel-row from memory made every lane hit its own 128-B line (~64 cycles
@@ -161,8 +161,8 @@ __global__ __launch_bounds__(256) void k_input_linear_f16(
   __syncthreads();
   const int chunk = threadIdx.x & 15;
   const f16x8 bias = bs[chunk];
-  const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 4);
-  for (int64_t node = (int64_t)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4); node < n;
+  const int64_t stride = (int64_t)blocks * (blockDim.x >> 4);
+  for (int64_t node = (int64_t)block * (blockDim.x >> 4) + (threadIdx.x >> 4); node < n;
        node += stride) {
     float xv[kInDim];
 #pragma unroll
@@ -178,6 +178,12 @@ __global__ __launch_bounds__(256) void k_input_linear_f16(
     }
     *reinterpret_cast<f16x8*>(h + node * kHidden + chunk * 8) = out;
   }
+}
+
+__global__ __launch_bounds__(256) void k_input_linear_f16(
+    const float* __restrict__ x, const f16* __restrict__ w_in, const f16* __restrict__ b_in,
+    f16* __restrict__ h, int n) {
+  input_linear_block(x, w_in, b_in, h, n, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------
@@ -794,12 +800,15 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
 
   const int64_t items = n * 16;
   enc->mark(s, 0);
-  if (use_dma && dma_tiles > 0 && tap_stage != 0)   // tile plans: once for all layers
-    k_tile_plan<<<dma_tiles, kThreads2, 0, s>>>(row_ptr, col, typ, (int)n, plans);
   {
     const int64_t blocks = (items + 255) / 256;
-    k_input_linear_f16<<<(int)(blocks > 2048 ? 2048 : blocks), 256, 0, s>>>(
-        x, enc->f16.w_in, enc->f16.b_in, ha, (int)n);
+    const int linear_blocks = (int)(blocks > 2048 ? 2048 : blocks);
+    if (use_dma && tap_stage != 0)   // + tile plans, once for all layers, in the same launch
+      k_encode_setup<<<dma_tiles + linear_blocks, 256, 0, s>>>(
+          x, enc->f16.w_in, enc->f16.b_in, ha, (int)n, row_ptr, col, typ, plans, dma_tiles);
+    else
+      k_input_linear_f16<<<linear_blocks, 256, 0, s>>>(x, enc->f16.w_in, enc->f16.b_in, ha,
+                                                       (int)n);
   }
   enc->mark(s, 1);
   const int stop = tap_stage >= 0 ? tap_stage : enc->layers;
