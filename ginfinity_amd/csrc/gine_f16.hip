@@ -541,7 +541,6 @@ __global__ __launch_bounds__(kThreads, 2) void k_gine_layer_f16(
 #endif
 }
 
-#include "gine_layer_dma.inc"
 
 // ---------------------------------------------------------------------------------
 // head + normalise
@@ -730,6 +729,8 @@ __global__ __launch_bounds__(256) void k_copy_rows_f16(const f16* __restrict__ s
     reinterpret_cast<f16x8*>(dst)[i] = reinterpret_cast<const f16x8*>(src)[i];
 }
 
+#include "gine_layer_dma.inc"
+
 int persistent_grid(int num_tiles) {
   int g = num_tiles < 256 ? num_tiles : 256;
   g = (g + 7) & ~7;  // whole XCD rounds (TileWalk divides by 8)
@@ -821,20 +822,33 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
         reinterpret_cast<const void*>(&k_gine_layer_f16<false>),
         hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLayerBytes));
     GFY_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&k_gine_layer_dma<true>),
+        reinterpret_cast<const void*>(&k_gine_layer_dma<true, false>),
         hipFuncAttributeMaxDynamicSharedMemorySize, k2Bytes));
     GFY_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&k_gine_layer_dma<false>),
+        reinterpret_cast<const void*>(&k_gine_layer_dma<false, false>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, k2Bytes));
+    GFY_CHECK_HIP(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&k_gine_layer_dma<true, true>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, k2Bytes));
+    GFY_CHECK_HIP(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&k_gine_layer_dma<false, true>),
         hipFuncAttributeMaxDynamicSharedMemorySize, k2Bytes));
     lds_opt_in = true;
   }
+  // fp16 output of a full encode: the last layer's launch runs the head as well
+  const bool fuse_head = use_dma && tap_stage < 0 && out_dtype == GFY_F16 && stop > 0 && n >= kT2 &&
+                         !getenv("GFY_SEPARATE_HEAD");
   for (int l = 0; l < stop; ++l) {
-    if (use_dma && enc->residual)
-      k_gine_layer_dma<true><<<dma_grid, kThreads2, k2Bytes, s>>>(
-          enc->f16.layer[l], ha, hb, row_ptr, col, typ, plans, (int)n, dma_tiles);
-    else if (use_dma)
-      k_gine_layer_dma<false><<<dma_grid, kThreads2, k2Bytes, s>>>(
-          enc->f16.layer[l], ha, hb, row_ptr, col, typ, plans, (int)n, dma_tiles);
+    const bool with_head = fuse_head && l == stop - 1;
+#define GFY_LAUNCH_DMA(RES, HEAD)                                                        \
+  k_gine_layer_dma<RES, HEAD><<<dma_grid, kThreads2, k2Bytes, s>>>(                      \
+      enc->f16.layer[l], ha, hb, row_ptr, col, typ, plans, (int)n, dma_tiles, enc->f16.head, \
+      out_rows, (f16*)out, normalise)
+    if (use_dma && enc->residual && with_head) GFY_LAUNCH_DMA(true, true);
+    else if (use_dma && enc->residual) GFY_LAUNCH_DMA(true, false);
+    else if (use_dma && with_head) GFY_LAUNCH_DMA(false, true);
+    else if (use_dma) GFY_LAUNCH_DMA(false, false);
+#undef GFY_LAUNCH_DMA
     else if (enc->residual)
       k_gine_layer_f16<true><<<grid, kThreads, kLdsLayerBytes, s>>>(
           enc->f16.layer[l], ha, hb, row_ptr, col, typ, (int)n, num_tiles);
@@ -850,6 +864,11 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
     const int64_t chunks = n * 16;
     int g = (int)((chunks + 255) / 256);
     k_copy_rows_f16<<<g > 2048 ? 2048 : g, 256, 0, s>>>(ha, (f16*)out, chunks);
+    GFY_CHECK_HIP(hipGetLastError());
+    return GFY_OK;
+  }
+  if (fuse_head) {
+    enc->mark(s, 2 + enc->layers);
     GFY_CHECK_HIP(hipGetLastError());
     return GFY_OK;
   }
