@@ -40,17 +40,6 @@ void pack_b_fragments(const f16* w, int n_out, int k_in, f16* frag) {
                 8 * (lane >> 5) + j];
 }
 
-// 16x16x32 MFMA A-operand order: frag[tile][ks][lane][j] = w[16 tile + (lane & 15)][32 ks + 8 (lane >> 4) + j]
-void pack_a16_fragments(const f16* w, int n_out, int k_in, f16* frag) {
-  const int tiles = n_out / 16, ksteps = k_in / 32;
-  for (int tile = 0; tile < tiles; ++tile)
-    for (int ks = 0; ks < ksteps; ++ks)
-      for (int lane = 0; lane < 64; ++lane)
-        for (int j = 0; j < 8; ++j)
-          frag[(((size_t)tile * ksteps + ks) * 64 + lane) * 8 + j] =
-              w[(size_t)(16 * tile + (lane & 15)) * k_in + 32 * ks + 8 * (lane >> 4) + j];
-}
-
 namespace {
 
 constexpr uint32_t kMagic = 0x31594647u;  // 'GFY1'
@@ -153,7 +142,7 @@ int gfy_encoder_create(const void* weight_pack_host, size_t bytes,
   Blob blob;
   // offsets first (pointers are fixed up after the single upload)
   struct LayerOff {
-    size_t table, w0, w0x, b0, alpha, shift, w1, w1x, b1, lg, lb;     // f16 mode
+    size_t table, w0, b0, alpha, shift, w1, b1, lg, lb;               // f16 mode
     size_t ftable, fw0, fb0, falpha, fshift, fw1, fb1, flg, flb;      // f32 mode
     float scale, one_plus_eps;
   };
@@ -208,13 +197,9 @@ int gfy_encoder_create(const void* weight_pack_host, size_t bytes,
       for (size_t i = 0; i < tmp.size(); ++i) tmp[i] = rh(w0[i]);
       o.w0 = blob.reserve(tmp.size() * sizeof(f16));
       pack_b_fragments(tmp.data(), M, H, blob.at<f16>(o.w0));
-      o.w0x = blob.reserve(tmp.size() * sizeof(f16));
-      pack_a16_fragments(tmp.data(), M, H, blob.at<f16>(o.w0x));
       for (size_t i = 0; i < tmp.size(); ++i) tmp[i] = rh(w1[i]);
       o.w1 = blob.reserve(tmp.size() * sizeof(f16));
       pack_b_fragments(tmp.data(), H, M, blob.at<f16>(o.w1));
-      o.w1x = blob.reserve(tmp.size() * sizeof(f16));
-      pack_a16_fragments(tmp.data(), H, M, blob.at<f16>(o.w1x));
       o.b0 = blob.reserve(M * sizeof(f16));
       o.alpha = blob.reserve(M * 4);
       o.shift = blob.reserve(M * 4);
@@ -331,8 +316,6 @@ int gfy_encoder_create(const void* weight_pack_host, size_t bytes,
       d.bn_alpha = F32p(o.alpha);
       d.bn_shift = F32p(o.shift);
       d.w1_frag = H16(o.w1);
-      d.w0_frag16 = H16(o.w0x);
-      d.w1_frag16 = H16(o.w1x);
       d.b1 = H16(o.b1);
       d.ln_gamma = H16(o.lg);
       d.ln_beta = H16(o.lb);

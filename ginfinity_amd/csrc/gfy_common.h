@@ -60,8 +60,6 @@ struct LayerF16 {
   const float* bn_alpha;  // [256]  invstd * gamma          (fp32, from fp16-rounded buffers)
   const float* bn_shift;  // [256]  beta - mean * alpha
   const f16* w1_frag;     // mlp.4.weight in MFMA B-fragment order
-  const f16* w0_frag16;   // the same matrices as 16x16x32 MFMA A-operand fragments:
-  const f16* w1_frag16;   //   [out/16][k/32][lane][8]: W[16 tile + (lane & 15)][32 ks + 8 (lane >> 4) + j]
   const f16* b1;          // [128]
   const f16* ln_gamma;    // [128]
   const f16* ln_beta;     // [128]

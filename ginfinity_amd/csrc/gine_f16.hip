@@ -1,34 +1,32 @@
-// fp16-mode GINE encode for gfx950 (MI355X): input Linear, fused GINE layer,
-// head + float64 L2 normalise.
+// fp16-mode GINE encode for gfx950 (MI355X): per-encode setup (tile plans + input
+// Linear), fused GINE layer, head + float64 L2 normalise.
 //
 // Reference ops replaced (src/ginfinity):
-//   _model.py:67      input Linear(7,128)                 -> k_input_linear_f16
+//   _model.py:67      input Linear(7,128)                 -> k_encode_setup / k_input_linear_f16
 //   _model.py:41-46   message / aggregate / (1+eps)x / MLP |
-//   _model.py:34-36   Linear-BatchNorm-ReLU-Linear         |-> k_gine_layer_f16
+//   _model.py:34-36   Linear-BatchNorm-ReLU-Linear         |-> k_gine_layer_f16  (gine_layer.inc)
 //   _model.py:69-71   LayerNorm + residual                 |
-//   _model.py:72      head Linear-ReLU-Linear              |-> k_head_f16
-//   api.py:250-259    fp64 normalise, core rows, dtype     |
+//   _model.py:72      head Linear-ReLU-Linear              |-> second pass of the last layer's
+//   api.py:250-259    fp64 normalise, core rows, dtype     |   launch (fp16 out) / k_head_f16
 //
 // Numerics contract (oracle/gine_numpy.py): every reference op
 // boundary rounds to fp16 in-register; arithmetic inside an op is fp32
-// (fp64 for LayerNorm moments and the final normalise).  v_pk_add_f16 /
-// v_pk_mul_f16 are used where "fp32 op then round" and the native fp16 op
-// agree exactly (sum/product of two fp16 values: 24 >= 2*11+2 bits).
+// (fp64 for the final normalise).  v_pk_add_f16 / v_pk_mul_f16 are used where
+// "fp32 op then round" and the native fp16 op agree exactly (sum/product of two
+// fp16 values: 24 >= 2*11+2 bits).
 //
-// Layer kernel, one 512-thread workgroup (8 waves) per CU, persistent over
-// 64-node tiles; tiles are dealt so that each XCD owns a contiguous node range
-// (backbone / skip-2 neighbours then hit that XCD's L2):
-//   A  gather-sum   16 lanes x 16 B per node row, CSR in-edges in COO order,
-//                   fp32 accumulate, z -> LDS (fp16, XOR-swizzled 16-B chunks)
-//   B  GEMM1        U^T = W0 . Z^T on v_mfma_f32_32x32x16_f16, W0 fragments live
-//                   in registers for the whole launch; epilogue bias, round,
-//                   BatchNorm fma, round, ReLU -> LDS
+// One tile of the layer kernel goes through four phases behind workgroup barriers:
+//   A  gather-sum   16 lanes x 16 B per node row, in-edges in CSR (= COO) order out of
+//                   LDS, fp32 accumulate, z -> LDS (fp16, XOR-swizzled 16-B chunks)
+//   B  GEMM1        U^T = W0 . Z^T on v_mfma_f32_32x32x16_f16, W0 fragments live in
+//                   registers for the whole launch; epilogue bias, round, BatchNorm fma,
+//                   round, ReLU -> LDS
 //   C  GEMM2        W^T = W1 . V^T, W1 fragments in registers; bias, round -> LDS
-//   D  LayerNorm    fp64 moments over 16 lanes, fma-fma affine, round, residual
-//                   add, 16-B coalesced store of the new hidden row
+//   D  LayerNorm    fp32 two-pass moments over 16 lanes (DPP), fma-fma affine, round,
+//                   residual add, 16-B coalesced store of the new hidden row
 // The node index sits on the MFMA lane (C^T form), so each lane's 4 consecutive
 // accumulator registers are 4 consecutive channels of one node: 8-byte LDS
-// writes, no transposition.
+// writes, no transposition.  Schedule, LDS-DMA look-ahead and tile plans: gine_layer.inc.
 #include <cstdlib>
 
 #include "gfy_common.h"
@@ -36,27 +34,8 @@
 namespace gfy {
 namespace {
 
-constexpr int kTile = 64;       // nodes per tile
-constexpr int kThreads = 512;   // 8 waves, 2 per SIMD
-
-// ---- LDS map of the layer kernel (bytes) -----------------------------------------
-constexpr int kLdsZW = 0;                       // 64 x 256 B  z, later w
-constexpr int kLdsV = kLdsZW + kTile * 256;     // 64 x 512 B  v
-constexpr int kLdsTable = kLdsV + kTile * 512;  // 16 x 128 f16 edge table
-constexpr int kLdsB0 = kLdsTable + kMaxEdgeTypes * kHidden * 2;
-constexpr int kLdsAlpha = kLdsB0 + kMlp * 4;    // b0 is kept widened to fp32
-constexpr int kLdsShift = kLdsAlpha + kMlp * 4;
-constexpr int kLdsB1 = kLdsShift + kMlp * 4;
-// CSR slice of a tile, double-buffered (tile t is consumed while t+1 is fetched)
-constexpr int kMetaCap = 1024;                    // in-edges of one 64-node tile held in LDS
-constexpr int kMetaRp = 0;                        // int[80]   row_ptr[base .. base+64]
-constexpr int kMetaCol = 320;                     // int[kMetaCap]
-constexpr int kMetaTyp = kMetaCol + kMetaCap * 4; // u8[kMetaCap]
-constexpr int kMetaBytes = kMetaTyp + kMetaCap;
-constexpr int kLdsMeta = kLdsB1 + kHidden * 2;
-constexpr int kLdsLayerBytes = kLdsMeta + 2 * kMetaBytes;
-constexpr int kGatherSlots = 8;                   // neighbour rows in flight per node row
-constexpr int kSlotsA = 6;                        // ... in the single-role kernel (2 rows per thread)
+constexpr int kTile = 64;       // nodes per tile of the stand-alone head kernel
+constexpr int kThreads = 512;   // ... and its workgroup: 8 waves, 2 per SIMD
 
 // 16-byte chunk `chunk` of row `row`, XOR-swizzled so that the 16 lanes of one
 // ds_read_b128 lane group (16 distinct rows, same chunk) hit 16 different slots.
@@ -185,362 +164,6 @@ __global__ __launch_bounds__(256) void k_input_linear_f16(
     f16* __restrict__ h, int n) {
   input_linear_block(x, w_in, b_in, h, n, blockIdx.x, gridDim.x);
 }
-
-// ---------------------------------------------------------------------------------
-// fused GINE layer
-// ---------------------------------------------------------------------------------
-template <bool kResidual>
-__global__ __launch_bounds__(kThreads, 2) void k_gine_layer_f16(
-    const LayerF16 p, const f16* __restrict__ h_in, f16* __restrict__ h_out,
-    const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
-    const uint8_t* __restrict__ typ, int n, int num_tiles) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const zw = smem + kLdsZW;
-  char* const vt = smem + kLdsV;
-  f16* const table = reinterpret_cast<f16*>(smem + kLdsTable);
-  float* const b0s = reinterpret_cast<float*>(smem + kLdsB0);
-  float* const alphas = reinterpret_cast<float*>(smem + kLdsAlpha);
-  float* const shifts = reinterpret_cast<float*>(smem + kLdsShift);
-  f16* const b1s = reinterpret_cast<f16*>(smem + kLdsB1);
-
-  const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
-  const int r = lane & 31, hq = lane >> 5;
-  const int chunk = t & 15, rsub = t >> 4;  // gather / LayerNorm mapping
-
-  // Prologue.  Three dependent round trips are unavoidable before the first tile can
-  // be reduced (row_ptr -> col/typ -> neighbour rows, ~1.3 us each under load), so
-  // the row_ptr request goes out first and the per-launch constants and the weight
-  // fragments travel in its shadow (vmcnt retires in order: nothing queued before
-  // row_ptr delays it).
-  STAMP(st_begin);
-  TileWalk walk(num_tiles);
-  int buf = 0;
-  const bool any_tile = walk.valid(num_tiles);
-  int rp_first = 0;
-  if (any_tile && t <= kTile) {
-    const int base0 = walk.tile() * kTile;
-    rp_first = row_ptr[base0 + t < n ? base0 + t : n];
-  }
-  // weight fragments -> registers, kept for every tile of this workgroup
-  f16x8 w0f[8], w1f[16];
-  {
-    const f16x8* w0p = reinterpret_cast<const f16x8*>(p.w0_frag) + (wave * 8) * 64 + lane;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) w0f[ks] = w0p[ks * 64];
-    const f16x8* w1p =
-        reinterpret_cast<const f16x8*>(p.w1_frag) + ((wave >> 1) * 16) * 64 + lane;
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) w1f[ks] = w1p[ks * 64];
-  }
-  const f16x8 gamma8 = reinterpret_cast<const f16x8*>(p.ln_gamma)[chunk];
-  const f16x8 beta8 = reinterpret_cast<const f16x8*>(p.ln_beta)[chunk];
-  const f16 scale16 = (f16)p.scale;
-  if (any_tile && t <= kTile)
-    reinterpret_cast<int*>(smem + kLdsMeta + kMetaRp)[t] = rp_first;
-  __syncthreads();
-  if (any_tile) {   // col/typ of the first tile: second round trip
-    char* meta = smem + kLdsMeta;
-    const int e0 = reinterpret_cast<const int*>(meta + kMetaRp)[0];
-    const int cnt = reinterpret_cast<const int*>(meta + kMetaRp)[kTile] - e0;
-    if (cnt <= kMetaCap)
-      for (int i = t; i < cnt; i += kThreads) {
-        reinterpret_cast<int*>(meta + kMetaCol)[i] = col[e0 + i];
-        reinterpret_cast<uint8_t*>(meta + kMetaTyp)[i] = typ[e0 + i];
-      }
-  }
-  // per-launch constants -> LDS
-  for (int i = t; i < kMaxEdgeTypes * kHidden / 8; i += kThreads)
-    reinterpret_cast<f16x8*>(table)[i] =
-        reinterpret_cast<const f16x8*>(p.edge_table)[i];
-  if (t < kMlp) b0s[t] = (float)p.b0[t];
-  if (t < kMlp / 4) {
-    reinterpret_cast<f32x4*>(alphas)[t] = reinterpret_cast<const f32x4*>(p.bn_alpha)[t];
-    reinterpret_cast<f32x4*>(shifts)[t] = reinterpret_cast<const f32x4*>(p.bn_shift)[t];
-  }
-  if (t < kHidden / 8)
-    reinterpret_cast<f16x8*>(b1s)[t] = reinterpret_cast<const f16x8*>(p.b1)[t];
-  __syncthreads();
-#ifdef GFY_STAMPS
-  {
-    STAMP(st_pro);
-    if (t == 0 && blockIdx.x < 256) g_stamps[blockIdx.x][6] += st_pro - st_begin;
-  }
-#endif
-
-  for (; walk.valid(num_tiles); walk.next(), buf ^= 1) {
-    const int base = walk.tile() * kTile;
-    const char* meta = smem + kLdsMeta + buf * kMetaBytes;
-    char* meta_next = smem + kLdsMeta + (buf ^ 1) * kMetaBytes;
-    STAMP(st0);
-    TileWalk ahead = walk;
-    ahead.next();
-    const bool has_next = ahead.valid(num_tiles);
-    const int next_base = ahead.tile() * kTile;
-    f16x8 hself[2];
-
-    // row_ptr of the NEXT tile: issued now, parked in LDS after the gather
-    int rp_next = 0;
-    if (has_next && t <= kTile) {
-      const int node = next_base + t < n ? next_base + t : n;
-      rp_next = row_ptr[node];
-    }
-
-    // ---- A: gather-sum -> z --------------------------------------------------
-    // Both node rows of a thread are fetched before either is reduced, slot fetches
-    // are branch-free (clamped index; a slot beyond the in-degree re-reads the
-    // node's own row, already in flight).  Measured alternatives that did NOT help
-    // (profiles/README.md): staging the tile + a +-2 halo in LDS and reading the
-    // backbone / skip-2 neighbours from there, and a wave-specialised pipeline
-    // (gine_layer_ws.inc).
-    const int* rp = reinterpret_cast<const int*>(meta + kMetaRp);
-    const int e_base = rp[0];
-    const bool staged = rp[kTile] - e_base <= kMetaCap;   // tile's edges are in LDS
-    const int* col_l = reinterpret_cast<const int*>(meta + kMetaCol);
-    const uint8_t* typ_l = reinterpret_cast<const uint8_t*>(meta + kMetaTyp);
-    const char* hbytes = reinterpret_cast<const char*>(h_in);
-    if (staged) {
-      int lo[2], hi[2];
-      f16x8 hv[2][kSlotsA];
-      int ty[2][kSlotsA];
-#pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
-        const int row = pass * 32 + rsub;
-        const int node = base + row < n ? base + row : n - 1;
-        lo[pass] = rp[row] - e_base;
-        hi[pass] = base + row < n ? rp[row + 1] - e_base : lo[pass];
-        hself[pass] = *reinterpret_cast<const f16x8*>(
-            hbytes + ((uint32_t)node * 256u + (uint32_t)chunk * 16u));
-#pragma unroll
-        for (int i = 0; i < kSlotsA; ++i) {
-          const bool valid = lo[pass] + i < hi[pass];
-          const int at = valid ? lo[pass] + i : 0;
-          const uint32_t s_i = valid ? (uint32_t)col_l[at] : (uint32_t)node;
-          ty[pass][i] = typ_l[at];
-          hv[pass][i] = *reinterpret_cast<const f16x8*>(
-              hbytes + (s_i * 256u + (uint32_t)chunk * 16u));
-        }
-      }
-#pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
-        const int row = pass * 32 + rsub;
-        float acc[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-#pragma unroll
-        for (int i = 0; i < kSlotsA; ++i) {
-          if (lo[pass] + i < hi[pass]) {   // COO order: slot i is the i-th in-edge
-            const f16x8 ev = *reinterpret_cast<const f16x8*>(
-                table + ty[pass][i] * kHidden + chunk * 8);
-            const f16x8 m = __builtin_elementwise_max(hv[pass][i] + ev, zero8());
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += (float)m[j];
-          }
-        }
-        for (int e = lo[pass] + kSlotsA; e < hi[pass]; ++e) {  // in-degree > kSlotsA
-          const uint32_t s0 = (uint32_t)col_l[e];
-          const f16x8 h0 = *reinterpret_cast<const f16x8*>(
-              hbytes + (s0 * 256u + (uint32_t)chunk * 16u));
-          const f16x8 ev = *reinterpret_cast<const f16x8*>(table + typ_l[e] * kHidden + chunk * 8);
-          const f16x8 m0 = __builtin_elementwise_max(h0 + ev, zero8());
-#pragma unroll
-          for (int j = 0; j < 8; ++j) acc[j] += (float)m0[j];
-        }
-        f16x8 agg;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) agg[j] = (f16)acc[j];   // ONE rounding of the fp32 sum
-        f16x8 z = hself[pass] * scale16 + agg;   // R(R(s*h) + a): two fp16 ops
-        if (base + row >= n) {
-          z = zero8();
-          hself[pass] = zero8();
-        }
-        *reinterpret_cast<f16x8*>(zw + off256(row, chunk)) = z;
-      }
-    } else {
-#pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {   // oversized tile (hubs): CSR from memory
-        const int row = pass * 32 + rsub;
-        const int node = base + row;
-        f16x8 z = zero8();
-        hself[pass] = zero8();
-        if (node < n) {
-          const f16x8 hs = *reinterpret_cast<const f16x8*>(
-              h_in + (size_t)node * kHidden + chunk * 8);
-          float acc[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-          for (int e = rp[row]; e < rp[row + 1]; ++e) {
-            const f16x8 h0 = *reinterpret_cast<const f16x8*>(
-                h_in + (size_t)col[e] * kHidden + chunk * 8);
-            const f16x8 ev = *reinterpret_cast<const f16x8*>(table + typ[e] * kHidden + chunk * 8);
-            const f16x8 m0 = __builtin_elementwise_max(h0 + ev, zero8());
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += (float)m0[j];
-          }
-          f16x8 agg;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) agg[j] = (f16)acc[j];
-          z = hs * scale16 + agg;
-          hself[pass] = hs;
-        }
-        *reinterpret_cast<f16x8*>(zw + off256(row, chunk)) = z;
-      }
-    }
-    STAMP(st_a0);
-    if (has_next && t <= kTile) reinterpret_cast<int*>(meta_next + kMetaRp)[t] = rp_next;
-    __syncthreads();
-    STAMP(st1);
-
-    // col/typ of the NEXT tile: issued before the GEMMs, parked in LDS after phase D
-    int cn[2] = {0, 0};
-    int tn[2] = {0, 0};
-    int cnt_next = 0;
-    if (has_next) {
-      const int* rpn = reinterpret_cast<const int*>(meta_next + kMetaRp);
-      const int e0n = rpn[0];
-      cnt_next = rpn[kTile] - e0n;
-      if (cnt_next <= kMetaCap) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int i = t + k * kThreads;
-          if (i < cnt_next) {
-            cn[k] = col[e0n + i];
-            tn[k] = typ[e0n + i];
-          }
-        }
-      }
-    }
-
-    // ---- B: U^T = W0 . Z^T ; v = relu(R(BN(R(u + b0)))) -------------------------
-    {
-      // chain 0, then chain 1 with the epilogue of chain 0 in its shadow (an MFMA
-      // holds the issue port for 8 of its 32 cycles)
-      f32x16 acc0 = {0}, acc1 = {0};
-      f16x8 z1f[8];
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const f16x8 z0 = *reinterpret_cast<const f16x8*>(zw + off256(r, 2 * ks + hq));
-        z1f[ks] = *reinterpret_cast<const f16x8*>(zw + off256(32 + r, 2 * ks + hq));
-        acc0 = mfma(w0f[ks], z0, acc0);
-      }
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) acc1 = mfma(w0f[ks], z1f[ks], acc1);
-      // epilogue on 4-wide vectors so that hipcc emits the packed forms
-      // (v_pk_add_f32, v_cvt_pk_f16_f32, v_pk_fma_f32, v_pk_max_f16): the scalar
-      // spelling cost ~12 VALU instructions per value and made this phase
-      // issue-bound (profiles/README.md)
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int c0 = wave * 32 + 8 * g + 4 * hq;  // 4 consecutive channels
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(b0s + c0);
-          const f32x4 al = *reinterpret_cast<const f32x4*>(alphas + c0);
-          const f32x4 sh = *reinterpret_cast<const f32x4*>(shifts + c0);
-          f32x4 a4;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) a4[i] = half == 0 ? acc0[4 * g + i] : acc1[4 * g + i];
-          const f16x4 u4 = __builtin_convertvector(a4 + b4, f16x4);               // R(acc + b0)
-          const f32x4 y4 = __builtin_elementwise_fma(__builtin_convertvector(u4, f32x4), al, sh);
-          const f16x4 zero4 = {0, 0, 0, 0};
-          const f16x4 vv = __builtin_elementwise_max(__builtin_convertvector(y4, f16x4), zero4);
-          *reinterpret_cast<f16x4*>(vt + off512(32 * half + r, c0 >> 3) + hq * 8) = vv;
-        }
-      }
-    }
-    __syncthreads();
-    STAMP(st2);
-
-    // ---- C: W^T = W1 . V^T ; w = R(acc + b1) --------------------------------------
-    {
-      const int nt = wave & 1, ct = wave >> 1;
-      f32x16 acc = {0};
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const f16x8 v8 =
-            *reinterpret_cast<const f16x8*>(vt + off512(32 * nt + r, 2 * ks + hq));
-        acc = mfma(w1f[ks], v8, acc);
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int c0 = ct * 32 + 8 * g + 4 * hq;
-        const f32x4 b4 = __builtin_convertvector(*reinterpret_cast<const f16x4*>(b1s + c0), f32x4);
-        f32x4 a4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a4[i] = acc[4 * g + i];
-        const f16x4 wv = __builtin_convertvector(a4 + b4, f16x4);
-        *reinterpret_cast<f16x4*>(zw + off256(32 * nt + r, c0 >> 3) + hq * 8) = wv;
-      }
-    }
-    __syncthreads();
-    STAMP(st3);
-
-    // ---- D: LayerNorm, residual, store -----------------------------------------
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      const int row = pass * 32 + rsub;
-      const int node = base + row;
-      const f16x8 w8 = *reinterpret_cast<const f16x8*>(zw + off256(row, chunk));
-      float xf[8];
-      float sum = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        xf[j] = (float)w8[j];
-        sum += xf[j];
-      }
-      // two-pass fp32 moments over the 16 lanes of the row (DPP, no LDS round trip)
-      const float mean = row16_sum32(sum) * (1.0f / kHidden);
-      float sq = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float d = xf[j] - mean;
-        sq = __builtin_fmaf(d, d, sq);
-      }
-      const float var = row16_sum32(sq) * (1.0f / kHidden);
-      const float rstd = fast_rsqrt(var + 1e-5f);
-      const float offset = -rstd * mean;
-      f16x8 y;
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        y[j] = (f16)__builtin_fmaf(__builtin_fmaf(xf[j], rstd, offset),
-                                   (float)gamma8[j], (float)beta8[j]);
-      const f16x8 hn = kResidual ? (hself[pass] + y) : y;
-      if (node < n)
-        *reinterpret_cast<f16x8*>(h_out + (size_t)node * kHidden + chunk * 8) = hn;
-    }
-    if (has_next && cnt_next <= kMetaCap) {
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int i = t + k * kThreads;
-        if (i < cnt_next) {
-          reinterpret_cast<int*>(meta_next + kMetaCol)[i] = cn[k];
-          reinterpret_cast<uint8_t*>(meta_next + kMetaTyp)[i] = (uint8_t)tn[k];
-        }
-      }
-    }
-    __syncthreads();  // zw is rewritten by the next tile's gather; next meta is complete
-#ifdef GFY_STAMPS
-    {
-      STAMP(st4);
-      if (t == 0 && blockIdx.x < 256) {
-        g_stamps[blockIdx.x][0] += st_a0 - st0;   // gather, this wave
-        g_stamps[blockIdx.x][1] += st1 - st_a0;   // wait at the A->B barrier
-        g_stamps[blockIdx.x][2] += st2 - st1;     // GEMM1 + epilogue + barrier
-        g_stamps[blockIdx.x][3] += st3 - st2;     // GEMM2 + epilogue + barrier
-        g_stamps[blockIdx.x][4] += st4 - st3;     // LayerNorm + store + barrier
-        g_stamps[blockIdx.x][5] += 1;             // tiles
-      }
-    }
-#endif
-  }
-#ifdef GFY_STAMPS
-  {
-    STAMP(st_end);
-    if (t == 0 && blockIdx.x < 256) g_stamps[blockIdx.x][7] += st_end - st_begin;
-  }
-#endif
-}
-
 
 // ---------------------------------------------------------------------------------
 // head + normalise
@@ -729,7 +352,7 @@ __global__ __launch_bounds__(256) void k_copy_rows_f16(const f16* __restrict__ s
     reinterpret_cast<f16x8*>(dst)[i] = reinterpret_cast<const f16x8*>(src)[i];
 }
 
-#include "gine_layer_dma.inc"
+#include "gine_layer.inc"
 
 int persistent_grid(int num_tiles) {
   int g = num_tiles < 256 ? num_tiles : 256;
@@ -757,12 +380,11 @@ extern "C" int gfy_debug_stamps(unsigned long long* host /*[256][16]*/, int rese
 }
 #endif
 
-// two hidden-state buffers, each padded with spare rows behind the last node (the
-// wave-specialised kernel stores unconditionally; rows that do not exist land there)
+// two hidden-state buffers, each padded with spare rows behind the last node
 static size_t h_buffer_bytes(int64_t n) {
   return align_up((size_t)(n + 2 * kTile) * kHidden * sizeof(f16), 256);
 }
-// ... plus one plan per 32-node tile (gine_layer_dma.inc)
+// ... plus one plan per 32-node tile (gine_layer.inc)
 static size_t plan_bytes(int64_t n) {
   return align_up((size_t)((n + kT2 - 1) / kT2) * kPlanBytes, 256);
 }
@@ -786,27 +408,21 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
   f16* ha = (f16*)ws;
   f16* hb = (f16*)((char*)ws + h_buffer_bytes(n));
   char* plans = (char*)ws + 2 * h_buffer_bytes(n);
-  const int num_tiles = (int)((n + kTile - 1) / kTile);
+  const int num_tiles = (int)((n + kTile - 1) / kTile);   // stand-alone head kernel
   const int grid = persistent_grid(num_tiles);
-  const int dma_tiles = (int)((n + kT2 - 1) / kT2);
-  int dma_grid = dma_tiles < 512 ? dma_tiles : 512;   // two 256-thread workgroups per CU
-  dma_grid = (dma_grid + 7) & ~7;
-  if (const char* g = getenv("GFY_DMA_GRID")) dma_grid = atoi(g);   // diagnostic
-  // default: the LDS-DMA kernel (gine_layer_dma.inc); GFY_LAYER_KERNEL=v1 selects the
-  // first-generation kernel for A/B runs
-  static const bool use_dma = [] {
-    const char* v = getenv("GFY_LAYER_KERNEL");
-    return !v || v[0] == 'd';
-  }();
+  const int layer_tiles = (int)((n + kT2 - 1) / kT2);
+  int layer_grid = layer_tiles < 512 ? layer_tiles : 512;   // two 256-thread workgroups per CU
+  layer_grid = (layer_grid + 7) & ~7;                        // whole XCD rounds
+  if (const char* g = getenv("GFY_LAYER_GRID")) layer_grid = atoi(g);   // diagnostic
 
   const int64_t items = n * 16;
   enc->mark(s, 0);
   {
     const int64_t blocks = (items + 255) / 256;
     const int linear_blocks = (int)(blocks > 2048 ? 2048 : blocks);
-    if (use_dma && tap_stage != 0)   // + tile plans, once for all layers, in the same launch
-      k_encode_setup<<<dma_tiles + linear_blocks, 256, 0, s>>>(
-          x, enc->f16.w_in, enc->f16.b_in, ha, (int)n, row_ptr, col, typ, plans, dma_tiles);
+    if (tap_stage != 0)   // + tile plans, once for all layers, in the same launch
+      k_encode_setup<<<layer_tiles + linear_blocks, 256, 0, s>>>(
+          x, enc->f16.w_in, enc->f16.b_in, ha, (int)n, row_ptr, col, typ, plans, layer_tiles);
     else
       k_input_linear_f16<<<linear_blocks, 256, 0, s>>>(x, enc->f16.w_in, enc->f16.b_in, ha,
                                                        (int)n);
@@ -816,45 +432,34 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
   static bool lds_opt_in = false;   // > 64 KB of dynamic LDS needs an explicit opt-in
   if (!lds_opt_in) {
     GFY_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&k_gine_layer_f16<true>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLayerBytes));
-    GFY_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&k_gine_layer_f16<false>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLayerBytes));
-    GFY_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&k_gine_layer_dma<true, false>),
+        reinterpret_cast<const void*>(&k_gine_layer_f16<true, false>),
         hipFuncAttributeMaxDynamicSharedMemorySize, k2Bytes));
     GFY_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&k_gine_layer_dma<false, false>),
+        reinterpret_cast<const void*>(&k_gine_layer_f16<false, false>),
         hipFuncAttributeMaxDynamicSharedMemorySize, k2Bytes));
     GFY_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&k_gine_layer_dma<true, true>),
+        reinterpret_cast<const void*>(&k_gine_layer_f16<true, true>),
         hipFuncAttributeMaxDynamicSharedMemorySize, k2Bytes));
     GFY_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&k_gine_layer_dma<false, true>),
+        reinterpret_cast<const void*>(&k_gine_layer_f16<false, true>),
         hipFuncAttributeMaxDynamicSharedMemorySize, k2Bytes));
     lds_opt_in = true;
   }
   // fp16 output of a full encode: the last layer's launch runs the head as well
-  const bool fuse_head = use_dma && tap_stage < 0 && out_dtype == GFY_F16 && stop > 0 && n >= kT2 &&
+  // (GFY_SEPARATE_HEAD=1 keeps the stand-alone head kernel: A/B runs and parity tests)
+  const bool fuse_head = tap_stage < 0 && out_dtype == GFY_F16 && stop > 0 && n >= kT2 &&
                          !getenv("GFY_SEPARATE_HEAD");
   for (int l = 0; l < stop; ++l) {
     const bool with_head = fuse_head && l == stop - 1;
-#define GFY_LAUNCH_DMA(RES, HEAD)                                                        \
-  k_gine_layer_dma<RES, HEAD><<<dma_grid, kThreads2, k2Bytes, s>>>(                      \
-      enc->f16.layer[l], ha, hb, row_ptr, col, typ, plans, (int)n, dma_tiles, enc->f16.head, \
+#define GFY_LAUNCH_LAYER(RES, HEAD)                                                          \
+  k_gine_layer_f16<RES, HEAD><<<layer_grid, kThreads2, k2Bytes, s>>>(                        \
+      enc->f16.layer[l], ha, hb, row_ptr, col, typ, plans, (int)n, layer_tiles, enc->f16.head, \
       out_rows, (f16*)out, normalise)
-    if (use_dma && enc->residual && with_head) GFY_LAUNCH_DMA(true, true);
-    else if (use_dma && enc->residual) GFY_LAUNCH_DMA(true, false);
-    else if (use_dma && with_head) GFY_LAUNCH_DMA(false, true);
-    else if (use_dma) GFY_LAUNCH_DMA(false, false);
-#undef GFY_LAUNCH_DMA
-    else if (enc->residual)
-      k_gine_layer_f16<true><<<grid, kThreads, kLdsLayerBytes, s>>>(
-          enc->f16.layer[l], ha, hb, row_ptr, col, typ, (int)n, num_tiles);
-    else
-      k_gine_layer_f16<false><<<grid, kThreads, kLdsLayerBytes, s>>>(
-          enc->f16.layer[l], ha, hb, row_ptr, col, typ, (int)n, num_tiles);
+    if (enc->residual && with_head) GFY_LAUNCH_LAYER(true, true);
+    else if (enc->residual) GFY_LAUNCH_LAYER(true, false);
+    else if (with_head) GFY_LAUNCH_LAYER(false, true);
+    else GFY_LAUNCH_LAYER(false, false);
+#undef GFY_LAUNCH_LAYER
     f16* sw = ha;
     ha = hb;
     hb = sw;

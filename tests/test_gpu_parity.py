@@ -426,3 +426,21 @@ def test_abi_rejects_oversized_and_undersized_requests(gpu_encoder):
                             (1 << 24) + 1, 0, None, out.data_ptr(), native.GFY_F16, 1,
                             tiny.data_ptr(), 1 << 40, None)
     assert status == native.GFY_ERR_UNSUPPORTED
+
+
+def test_fused_head_equals_standalone_head(gpu_encoder, monkeypatch):
+    """fp16 output runs the head inside the last layer's launch; the stand-alone
+    head kernel (GFY_SEPARATE_HEAD=1, also the f32/f64-output path) must give the
+    same bytes — with and without dropped context rows, ragged last tile included."""
+    from ginfinity_amd import synthetic
+    for shard in (synthetic.arbitrary_shard(3, nodes=10_007, edges=40_000),   # context rows
+                  synthetic.roofline_shard(5, records=2, length=1_000)):      # all core
+        monkeypatch.delenv("GFY_SEPARATE_HEAD", raising=False)
+        fused = np.concatenate(gpu_encoder.encode_graphs(shard))
+        monkeypatch.setenv("GFY_SEPARATE_HEAD", "1")
+        alone = np.concatenate(gpu_encoder.encode_graphs(shard))
+        assert fused.dtype == np.float16 and fused.shape == alone.shape
+        assert np.array_equal(fused.view(np.uint16), alone.view(np.uint16))
+        as_f32 = np.concatenate(gpu_encoder.encode_graphs(shard, embedding_dtype=np.float32))
+        monkeypatch.delenv("GFY_SEPARATE_HEAD")
+        assert _maxabs(as_f32, fused) <= 6e-4    # one fp16 rounding of a unit-norm row

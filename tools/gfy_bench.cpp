@@ -141,14 +141,12 @@ int main(int argc, char** argv) {
     double sum[16] = {0};
     for (int b = 0; b < 256; ++b) for (int k = 0; k < 16; ++k) sum[k] += (double)st[b][k];
     {
-      const double launches = reps * 4.0 * 256;   // 4 layers, 256 workgroups
+      const double launches = reps * 4.0 * 256;   // 4 layers, first 256 workgroups
       double tmax = 0, tmin = 1e30;
       for (int b = 0; b < 256; ++b) { tmax = st[b][7] > tmax ? st[b][7] : tmax; tmin = st[b][7] < tmin ? st[b][7] : tmin; }
       printf("per workgroup launch: prologue %.0f cycles, whole kernel body %.0f cycles (min WG %.0f, max WG %.0f per launch)\n",
              sum[6] / launches, sum[7] / launches, tmin / (reps * 4.0), tmax / (reps * 4.0));
     }
-    printf("ws stamps per step: matrix GEMM1 %.0f waitB1 %.0f GEMM2 %.0f waitB2 %.0f | vector first-half %.0f second-half %.0f (steps %.0f)\n",
-           sum[0] / sum[5], sum[1] / sum[5], sum[2] / sum[5], sum[3] / sum[5], sum[4] / sum[5], sum[6] / sum[5], sum[5]);
     {
       static unsigned long long real[512][2];
       gfy_debug_real(&real[0][0]);

@@ -1,6 +1,6 @@
 """Per-basic-block instruction counts of one kernel in a hipcc -S listing.
 
-    python tools/isa_blocks.py layer.s k_gine_layer_dmaILb1 [first_line last_line]
+    python tools/isa_blocks.py layer.s k_gine_layer_f16ILb1ELb0 [first_line last_line]
 
 Prints, for every label (and barrier), the number of VALU / SALU / LDS / VMEM / MFMA
 instructions up to the next label, so that the hot path of a phase can be summed by hand.

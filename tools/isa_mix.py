@@ -1,6 +1,6 @@
 """Static instruction mix of one kernel in a hipcc -S listing, split at s_barrier.
 
-    python tools/isa_mix.py layer.s k_gine_layer_f16ILb1
+    python tools/isa_mix.py layer.s k_gine_layer_f16ILb1ELb0
 
 Counts are per static segment (program order), so loop tails / cold blocks laid out
 after a barrier are attributed to the segment they are printed in.
