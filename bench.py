@@ -5,16 +5,18 @@ shards (BASELINE.json configs[2]), fp16 model, inputs resident in HBM.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One step = one pass of the hot path over one shard: COO→CSR build, input
-Linear, 4 fused GINE layers, head + float64 L2 normalise, embeddings left on
-the device.  Multi-GPU: shards are independent, every rank encodes
+One step = one pass of the hot path over one shard: COO→CSR build (5 launches),
+per-encode setup (tile plans + input Linear, 1 launch), 4 fused GINE layer launches
+the last of which also runs head + float64 L2 normalise, embeddings left on the
+device.  Multi-GPU: shards are independent, every rank encodes
 its own shards, there is no data-path collective ("weak" scaling); the only
 communication is the barrier and the MAX-reduction of the elapsed time.
 
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   roofline      dominant kernel (k_gine_layer_f16): algorithmic bytes per launch
                 (512·N + 9·E + layer weights) ÷ its mean
-                duration measured with HIP events on the launch stream
+                duration (layers 1-3: the launches without the fused head) measured
+                with HIP events on the launch stream
   cpu_baseline  oracle/gine_torch.py (the reference's aten op sequence) timed on
                 this box's host cores on the same workload — N=1 only.
 """
@@ -61,10 +63,10 @@ def parse() -> argparse.Namespace:
 
 def measured_traffic(kernel: str):
     """HBM bytes per launch of ``kernel`` from the committed PMC passes
-    (profiles/r01b_traffic_pmc.json: rocprofv3 FETCH_SIZE/WRITE_SIZE, gfx950
+    (profiles/r01c_traffic_pmc.json: rocprofv3 FETCH_SIZE/WRITE_SIZE, gfx950
     half-count correction applied).  Counter passes cannot run inside this script;
     None if the file is absent."""
-    path = ROOT / "profiles" / "r01b_traffic_pmc.json"
+    path = ROOT / "profiles" / "r01c_traffic_pmc.json"
     try:
         return json.loads(path.read_text())["kernels"][kernel]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
@@ -174,7 +176,10 @@ def main() -> None:
             sums = times if sums is None else [a + b for a, b in zip(sums, times)]
         engine.set_timing(False)
         mean = [t / rounds for t in sums]
-        layer_ms = sum(mean[1:-1]) / (len(mean) - 2)
+        # marks: setup | layer 1 .. layer L | (stand-alone head: 0 for fp16 output, where
+        # the last layer's launch runs the head too)
+        plain_layers = mean[1:-2]
+        layer_ms = sum(plain_layers) / len(plain_layers)
         achieved = LAYER_BYTES / (layer_ms * 1e-3) / 1e9
         roofline = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -187,8 +192,8 @@ def main() -> None:
             "pipeline_frac": PIPELINE_BYTES * world * args.steps / elapsed / 1e9
                              / (HBM_PEAK_GBS * world),
         }
-        kernels = {"csr_build_ms": csr_ms / rounds, "input_linear_ms": mean[0],
-                   "layer_ms": mean[1:-1], "head_normalise_ms": mean[-1]}
+        kernels = {"csr_build_ms": csr_ms / rounds, "setup_plans_input_linear_ms": mean[0],
+                   "layer_ms": plain_layers, "last_layer_with_head_normalise_ms": mean[-2]}
 
     baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -169,8 +169,10 @@ class DeviceEncoder:
             self._handle, 1 if enabled else 0), "gfy_encoder_set_timing")
 
     def kernel_times_ms(self) -> list[float]:
-        """Device time of each kernel of the last ``encode`` (timing enabled):
-        [input Linear, layer 0.., head+normalise]."""
+        """Device time between the marks of the last ``encode`` (timing enabled):
+        [setup (tile plans + input Linear), layer 1 .. layer L, stand-alone head].
+        For fp16 output the last layer's launch runs the head + normalise as well
+        and the final entry is ~0."""
         buffer = (ctypes.c_float * 16)()
         count = ctypes.c_int()
         native.check(self._lib.gfy_encoder_get_timing(

@@ -130,7 +130,9 @@ int gfy_encode_hidden(gfy_encoder* encoder, const float* node_features,
  * figure).  While enabled, gfy_encode brackets each kernel with hipEvents on the
  * caller's stream (do not enable under graph capture).  gfy_encoder_get_timing
  * waits for the last gfy_encode and writes milliseconds to ms_host:
- * [0] input Linear, [1..layers] GINE layers, [layers+1] head+normalise;
+ * [0] per-encode setup (tile plans + input Linear), [1..layers] GINE layer
+ * launches, [layers+1] stand-alone head+normalise (fp16-model fp16 output: the
+ * last layer's launch runs the head too and this entry is ~0);
  * *count receives layers+2. */
 int gfy_encoder_set_timing(gfy_encoder* encoder, int enable);
 int gfy_encoder_get_timing(gfy_encoder* encoder, float* ms_host, int capacity,

@@ -1,0 +1,69 @@
+"""Condense the rocprofv3 --pmc passes of tools/profile_round.sh into the JSON files kept
+under profiles/ (mean counter value per dispatch and kernel).
+
+    python tools/pmc_summary.py r01c
+"""
+import collections
+import csv
+import json
+import re
+import sys
+from pathlib import Path
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01c"
+root = Path(__file__).resolve().parent.parent
+src = root / "gpurun_out" / tag
+
+
+def short(name: str) -> str:
+    m = re.search(r"(k_[a-z_0-9]+)(I[A-Za-z0-9_]*E)?", name)
+    if not m:
+        return name[:40]
+    base = m.group(1)
+    if base == "k_gine_layer_f16":          # <kResidual, kHead>
+        base += "<head>" if "ELb1EE" in name or "Lb1ELb1" in name and False else ""
+        if re.search(r"k_gine_layer_f16ILb[01]ELb1E", name):
+            base = "k_gine_layer_f16<+head>"
+    return base
+
+
+def means(path: Path):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for row in csv.DictReader(open(path)):
+        agg[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}
+
+
+traffic = collections.defaultdict(dict)
+for sub in sorted(src.glob("pmc_*")):
+    if sub.is_dir():
+        for kernel, counters in means(sub / "pmc_counter_collection.csv").items():
+            traffic[kernel].update(counters)
+for kernel, c in traffic.items():
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        c["hbm_bytes_per_launch"] = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+json.dump({
+    "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc TCC_* (three separate passes, "
+           "--kernel-trace only) -- ./tools/gfy_bench 60000 20 (tools/profile_round.sh); mean per "
+           "dispatch; workload = 60,000-node / 300,000-edge synthetic shard",
+    "units": "FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them",
+    "correction": "gfx950: FETCH_SIZE reports half the bytes of wide (16 B/lane) coalesced reads "
+                  "(MI355X_MICROARCH.md, HBM section) -> hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024",
+    "kernels": traffic}, open(root / "profiles" / f"{tag}_traffic_pmc.json", "w"), indent=1)
+
+sq = collections.defaultdict(dict)
+for sub in ("sq_a", "sq_b"):
+    path = src / sub / "sq_counter_collection.csv"
+    if path.exists():
+        for kernel, counters in means(path).items():
+            sq[kernel].update(counters)
+json.dump({
+    "how": "two rocprofv3 --pmc passes of 8 SQ counters over ./tools/gfy_bench 60000 20; mean per "
+           "dispatch, summed over the chip (SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count "
+           "quad-cycles per wave, SQ_VALU_MFMA_BUSY_CYCLES and SQ_LDS_* count cycles)",
+    "kernels": sq}, open(root / "profiles" / f"{tag}_layer_sq_pmc.json", "w"), indent=1)
+for kernel in sorted(traffic):
+    c = traffic[kernel]
+    print(f"{kernel:28s} FETCH {c.get('FETCH_SIZE', 0):9.1f} KiB  WRITE {c.get('WRITE_SIZE', 0):9.1f} KiB  "
+          f"-> {c.get('hbm_bytes_per_launch', 0) / 1e6:7.2f} MB/launch  "
+          f"TCC hit {c.get('TCC_HIT_sum', 0):9.0f} miss {c.get('TCC_MISS_sum', 0):9.0f}")
