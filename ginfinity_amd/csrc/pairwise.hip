@@ -171,15 +171,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_pairwise(const PairArgs p) {
         accs[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf, af0[ks], accs[0], 0, 0, 0);
         accs[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf, af1, accs[1], 0, 0, 0);
       }
+      if constexpr (kDense) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int jl = 64 * wb + 32 * bt + 8 * g + 4 * hq;  // 4 consecutive b-rows
-        const f32x4 sv = *reinterpret_cast<const f32x4*>(s_l + jl);
-        const f32x4 tv = *reinterpret_cast<const f32x4*>(t_l + jl);
+        for (int g = 0; g < 4; ++g) {
+          const int jl = 64 * wb + 32 * bt + 8 * g + 4 * hq;  // 4 consecutive b-rows
+          const f32x4 sv = *reinterpret_cast<const f32x4*>(s_l + jl);
+          const f32x4 tv = *reinterpret_cast<const f32x4*>(t_l + jl);
 #pragma unroll
-        for (int at = 0; at < 2; ++at) {
-          const int64_t ai = a0 + 64 * wa + 32 * at + r;
-          if constexpr (kDense) {
+          for (int at = 0; at < 2; ++at) {
+            const int64_t ai = a0 + 64 * wa + 32 * at + r;
             const float aterm = ai < p.n ? p.a_term[ai] : 0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -196,19 +196,55 @@ __global__ __launch_bounds__(kThreads, 2) void k_pairwise(const PairArgs p) {
                 p.dense[ai * p.m + j] = val;
               }
             }
-          } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              float key = __builtin_fmaf(accs[at][4 * g + i], sv[i], tv[i]);
-              const int j = (int)(j0 + jl + i);
-              if (may_exclude && (int64_t)j == ai + p.exclude_offset) key = __builtin_inff();
-              if (key < best[at]) {   // ascending j inside a lane: strict < keeps the lowest index
-                best[at] = key;
-                bidx[at] = j;
-              }
-            }
           }
         }
+      } else {
+        __builtin_amdgcn_sched_barrier(0);   // keep the next b-tile's operand reads behind us
+        // The contraction is only 128 deep, so an epilogue of fma + compare + two selects
+        // per element costs more vector cycles than the MFMAs that produced it.  Instead:
+        // 16 keys per a-row with packed fmas, their minimum with v_min3 (~1 instruction per
+        // element in all), and the position of the minimum is recovered only while some
+        // lane of the wave still improves its running best — soon rare.
+#pragma unroll
+        for (int at = 0; at < 2; ++at) {
+          const int64_t ai = a0 + 64 * wa + 32 * at + r;
+          f32x4 key[4];   // one a-row's 16 keys at a time (registers); s/t are re-read per a-tile
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int jl = 64 * wb + 32 * bt + 8 * g + 4 * hq;  // 4 consecutive b-rows
+            const f32x4 sv = *reinterpret_cast<const f32x4*>(s_l + jl);
+            const f32x4 tv = *reinterpret_cast<const f32x4*>(t_l + jl);
+            f32x4 a4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a4[i] = accs[at][4 * g + i];
+            key[g] = __builtin_elementwise_fma(a4, sv, tv);
+          }
+          if (may_exclude) {   // block-uniform, at most two tiles per block
+            // the one excluded b-row of this a-row, as a position among the lane's 16 keys
+            const int64_t off = ai + p.exclude_offset - (j0 + 64 * wb + 32 * bt + 4 * hq);
+            const int d = off >= 0 && off < 32 ? (int)off : 4;   // 4: not a position of this lane
+            const int slot = (d & 4) ? -1 : (d >> 3) * 4 + (d & 3);
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+              key[q >> 2][q & 3] = q == slot ? __builtin_inff() : key[q >> 2][q & 3];
+          }
+          float low = __builtin_fminf(key[0][0], key[0][1]);
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = (g == 0 ? 2 : 0); i < 4; i += 2)
+              low = __builtin_fminf(__builtin_fminf(low, key[g][i]), key[g][i + 1]);   // v_min3_f32
+          const bool better = low < best[at];   // strict: an earlier tile keeps a tie
+          if (__ballot(better)) {               // wave-uniform skip once the sweep has settled
+            int first = 15;                     // lowest position holding the minimum
+#pragma unroll
+            for (int q = 14; q >= 0; --q) first = key[q >> 2][q & 3] == low ? q : first;
+            const int j = (int)(j0 + 64 * wb + 32 * bt + 8 * (first >> 2) + 4 * hq + (first & 3));
+            best[at] = better ? low : best[at];
+            bidx[at] = better ? j : bidx[at];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     __syncthreads();
