@@ -156,6 +156,38 @@ int launch_pairwise_nearest(const void* a, int64_t n, const void* b, int64_t m,
                             hipStream_t s);
 size_t pairwise_workspace_bytes(int64_t n, int64_t m);
 
+// ---- LDS-DMA (global_load_lds_dwordx4) ---------------------------------------------
+// One wave instruction: lane L copies 16 bytes from its own global address to LDS
+// address lds + 16 L (lds is wave-uniform, in M0); inactive lanes move nothing.  No
+// VGPRs, and not visible to the compiler's waitcnt bookkeeping: the consumer waits with
+// dma_wait_all() / dma_wait_but().
+__device__ __forceinline__ void dma16(const void* gbase /* uniform */, uint32_t goff,
+                                      uint32_t lds) {
+  asm volatile(
+      "s_mov_b32 m0, %0\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2"
+      :
+      : "s"(lds), "v"(goff), "s"(gbase)
+      : "memory");
+}
+__device__ __forceinline__ void dma16_at(const void* lane_ptr, uint32_t lds) {   // 64-bit form
+  asm volatile(
+      "s_mov_b32 m0, %0\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off"
+      :
+      : "s"(lds), "v"(lane_ptr)
+      : "memory");
+}
+// The builtin (not an asm string) so that hipcc's own waitcnt bookkeeping learns that
+// nothing is outstanding: otherwise it guards the first use of every earlier-loaded
+// register with a vmcnt wait that would drain a look-ahead early.
+__device__ __forceinline__ void dma_wait_all() {
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0); expcnt, lgkmcnt untouched
+  asm volatile("" ::: "memory");
+}
+
 // W[n_out][k_in] (row-major fp16) -> MFMA 32x32x16 B-operand fragment order:
 // frag[(ntile * ksteps + ks) * 64 + lane][8] = W[32*ntile + (lane & 31)][16*ks + 8*(lane >> 5) + j]
 void pack_b_fragments(const f16* w, int n_out, int k_in, f16* frag);

@@ -9,7 +9,9 @@
 //
 // One kernel serves both outputs.  A workgroup (4 waves, 2x2) owns 128 a-rows,
 // whose MFMA fragments stay in registers, and sweeps its chunk of b-rows in
-// 128-row tiles staged through LDS (coalesced 256-B rows, XOR-swizzled chunks).
+// 128-row tiles that LDS-DMA (global_load_lds_dwordx4) lands in one of two LDS
+// buffers a tile ahead; every lane fetches the 16-byte chunk that belongs in its
+// slot of the XOR-swizzled layout, so no register ever holds b-rows in flight.
 // The product is taken as (B-tile) x (A-block)^T so the a-row sits on the MFMA
 // lane: the running best of an a-row is lane-local state and a lane's four
 // consecutive accumulator registers are four consecutive b-rows.
@@ -34,8 +36,10 @@ __device__ __forceinline__ int off256(int row, int chunk) {
 }
 
 // per-row (s, t) on the b side, (na or 1/|a|) on the a side
+// s/t are written for `padded` >= count rows: the rows past the end get key = +inf
 __global__ __launch_bounds__(256) void k_row_terms(const f16* __restrict__ rows, int64_t count,
-                                                   int metric, float* __restrict__ s_out,
+                                                   int64_t padded, int metric,
+                                                   float* __restrict__ s_out,
                                                    float* __restrict__ t_out,
                                                    float* __restrict__ a_term) {
   const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -58,6 +62,10 @@ __global__ __launch_bounds__(256) void k_row_terms(const f16* __restrict__ rows,
     }
     if (a_term) a_term[row] = metric == GFY_L2 ? ss : inv;
   }
+  if (row >= count && row < padded && chunk == 0 && s_out) {
+    s_out[row] = 0.f;
+    t_out[row] = __builtin_inff();   // never wins
+  }
 }
 
 struct PairArgs {
@@ -76,15 +84,15 @@ struct PairArgs {
   float* dense;         // [n][m]        (dense)
 };
 
+constexpr int kBufBytes = kTileB * 256 + 2 * kTileB * 4;   // b-tile + its (s, t)
+
 template <bool kDense>
 __global__ __launch_bounds__(kThreads, 2) void k_pairwise(const PairArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* tile = smem;                                            // b-tile: 128 x 256 B
-  float* s_l = reinterpret_cast<float*>(smem + kTileB * 256);   // [128]
-  float* t_l = s_l + kTileB;                                     // [128]
-  char* atile = smem + kTileB * 256 + 2 * kTileB * 4;           // a-block: 128 x 256 B, resident
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // two buffers
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int r = lane & 31, hq = lane >> 5;
   const int wa = wave & 1, wb = wave >> 1;  // wave owns a-rows [64wa,64wa+64), b-rows [64wb, 64wb+64) of each tile
   const int chunk = blockIdx.x / p.blocks_a;
@@ -93,20 +101,44 @@ __global__ __launch_bounds__(kThreads, 2) void k_pairwise(const PairArgs p) {
   const int64_t j_begin = (int64_t)chunk * p.chunk_rows;
   const int64_t j_end = j_begin + p.chunk_rows < p.m ? j_begin + p.chunk_rows : p.m;
 
-  // stage the a-block through LDS once (coalesced), then keep fragments in registers
-  for (int i = t; i < kBlockA * 16; i += kThreads) {
-    const int row = i >> 4, ch = i & 15;
-    f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (a0 + row < p.n) v = *reinterpret_cast<const f16x8*>(p.a + (a0 + row) * 128 + ch * 8);
-    *reinterpret_cast<f16x8*>(atile + off256(row, ch)) = v;
-  }
-  __syncthreads();
-  // a-tile 0 fragments stay in registers, a-tile 1 is re-read from LDS per use: the
-  // registers go to the b-tile that is in flight (a whole tile ahead)
-  f16x8 af0[8];
+  // one b-tile -> buffer `buf`: 128 rows as 32 DMA instructions (8 per wave, 4 rows each),
+  // (s, t) as one more by waves 0 and 1.  Rows past the end re-read the last row; their
+  // t is +inf (k_row_terms pads s/t to whole tiles).
+  auto request = [&](int64_t j0, int buf) {
+    const uint32_t base = lds0 + (uint32_t)buf * kBufBytes;
+    const int sub = lane >> 4, slot = lane & 15;
 #pragma unroll
-  for (int ks = 0; ks < 8; ++ks)
-    af0[ks] = *reinterpret_cast<const f16x8*>(atile + off256(64 * wa + r, 2 * ks + hq));
+    for (int q = 0; q < 8; ++q) {
+      const int g = wave * 8 + q;
+      const int row = 4 * g + sub;
+      int64_t j = j0 + row;
+      j = j < p.m ? j : p.m - 1;
+      dma16_at(p.b + j * 128 + (slot ^ (row & 15)) * 8, base + (uint32_t)g * 1024u);
+    }
+    if (wave < 2 && lane < 32)   // 128 floats = 32 lanes x 16 B
+      dma16_at((wave == 0 ? p.s : p.t) + j0 + lane * 4,
+               base + kTileB * 256 + (uint32_t)wave * (kTileB * 4));
+  };
+
+  // stage the a-block through LDS once (coalesced), then keep ALL its fragments in registers
+  {
+    char* atile = smem + kBufBytes;   // second buffer, not yet in use
+    for (int i = t; i < kBlockA * 16; i += kThreads) {
+      const int row = i >> 4, ch = i & 15;
+      f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (a0 + row < p.n) v = *reinterpret_cast<const f16x8*>(p.a + (a0 + row) * 128 + ch * 8);
+      *reinterpret_cast<f16x8*>(atile + off256(row, ch)) = v;
+    }
+  }
+  if (j_begin < j_end) request(j_begin, 0);
+  __syncthreads();
+  f16x8 af[2][8];
+#pragma unroll
+  for (int at = 0; at < 2; ++at)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      af[at][ks] = *reinterpret_cast<const f16x8*>(
+          smem + kBufBytes + off256(64 * wa + 32 * at + r, 2 * ks + hq));
 
   float best[2];
   int bidx[2];
@@ -116,38 +148,16 @@ __global__ __launch_bounds__(kThreads, 2) void k_pairwise(const PairArgs p) {
     bidx[at] = 0x7fffffff;
   }
 
-  // b-tiles are requested one iteration ahead (registers), written to LDS at the top
-  // of the iteration that consumes them: the round trip hides under the MFMAs
-  f16x8 pre[8];
-  float pre_s = 0.f, pre_t = __builtin_inff();
-  auto request = [&](int64_t j0) {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int i = t + q * kThreads;
-      const int row = i >> 4, ch = i & 15;
-      pre[q] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      if (j0 + row < p.m) pre[q] = *reinterpret_cast<const f16x8*>(p.b + (j0 + row) * 128 + ch * 8);
-    }
-    if (t < kTileB) {
-      const bool ok = j0 + t < p.m;
-      pre_s = ok ? p.s[j0 + t] : 0.f;
-      pre_t = ok ? p.t[j0 + t] : __builtin_inff();   // key = +inf: never wins
-    }
-  };
-  if (j_begin < j_end) request(j_begin);
-
-  for (int64_t j0 = j_begin; j0 < j_end; j0 += kTileB) {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int i = t + q * kThreads;
-      *reinterpret_cast<f16x8*>(tile + off256(i >> 4, i & 15)) = pre[q];
-    }
-    if (t < kTileB) {
-      s_l[t] = pre_s;
-      t_l[t] = pre_t;
-    }
+  int cur = 0;
+  for (int64_t j0 = j_begin; j0 < j_end; j0 += kTileB, cur ^= 1) {
+    // this wave's share of tile j0 has landed; the barrier publishes everybody's and tells
+    // us that the other buffer (tile j0 - 128, or the a-block) is no longer being read
+    dma_wait_all();
     __syncthreads();
-    if (j0 + kTileB < j_end) request(j0 + kTileB);
+    if (j0 + kTileB < j_end) request(j0 + kTileB, cur ^ 1);
+    const char* tile = smem + cur * kBufBytes;
+    const float* s_l = reinterpret_cast<const float*>(tile + kTileB * 256);
+    const float* t_l = s_l + kTileB;
 
     // does this tile contain an excluded (i, i + offset) pair of this block?
     const int64_t ex_lo = a0 + p.exclude_offset, ex_hi = ex_lo + kBlockA;
@@ -155,21 +165,21 @@ __global__ __launch_bounds__(kThreads, 2) void k_pairwise(const PairArgs p) {
 
 #pragma unroll
     for (int bt = 0; bt < 2; ++bt) {
-      // one 32-row b-tile at a time: 2 accumulators live (VGPR budget: the a-block
-      // fragments and the next b-tile in flight take 96 registers)
+      // one 32-row b-tile at a time: 2 accumulators live
       f32x16 accs[2];
 #pragma unroll
       for (int at = 0; at < 2; ++at)
 #pragma unroll
         for (int q = 0; q < 16; ++q) accs[at][q] = 0.f;
+      f16x8 bf[8];   // all operand reads of the 32-row b-tile before the first MFMA
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+        bf[ks] = *reinterpret_cast<const f16x8*>(tile + off256(64 * wb + 32 * bt + r, 2 * ks + hq));
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        const f16x8 bf = *reinterpret_cast<const f16x8*>(
-            tile + off256(64 * wb + 32 * bt + r, 2 * ks + hq));
-        const f16x8 af1 = *reinterpret_cast<const f16x8*>(
-            atile + off256(64 * wa + 32 + r, 2 * ks + hq));
-        accs[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf, af0[ks], accs[0], 0, 0, 0);
-        accs[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf, af1, accs[1], 0, 0, 0);
+        accs[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ks], af[0][ks], accs[0], 0, 0, 0);
+        accs[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ks], af[1][ks], accs[1], 0, 0, 0);
       }
       if constexpr (kDense) {
 #pragma unroll
@@ -247,8 +257,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_pairwise(const PairArgs p) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    __syncthreads();
   }
+  __syncthreads();   // the result merge below reuses the first buffer
 
   if constexpr (!kDense) {
     // merge the two lane halves (different b-rows, same a-row), then the two
@@ -336,8 +346,8 @@ PairWorkspace carve(void* base, int64_t n, int64_t m) {
     off += align_up(bytes, 256);
     return ptr;
   };
-  w.s = (float*)take((size_t)m * 4);
-  w.t = (float*)take((size_t)m * 4);
+  w.s = (float*)take((size_t)tiles_b * kTileB * 4);   // padded to whole tiles
+  w.t = (float*)take((size_t)tiles_b * kTileB * 4);
   w.a_term = (float*)take((size_t)n * 4);
   w.part_val = (float*)take((size_t)w.chunks * n * 4);
   w.part_idx = (int32_t*)take((size_t)w.chunks * n * 4);
@@ -345,7 +355,7 @@ PairWorkspace carve(void* base, int64_t n, int64_t m) {
   return w;
 }
 
-constexpr int kPairLds = kTileB * 256 + 2 * kTileB * 4 + kBlockA * 256;   // b-tile, (s,t), a-block
+constexpr int kPairLds = 2 * kBufBytes;   // two b-tile buffers (the second stages the a-block first)
 
 }  // namespace
 
@@ -360,8 +370,9 @@ int launch_pairwise_nearest(const void* a, int64_t n, const void* b, int64_t m,
               "gfy_pairwise_nearest: workspace %zu < required %zu", ws_bytes, w.bytes);
   const f16* ap = (const f16*)a;
   const f16* bp = (const f16*)b;
-  k_row_terms<<<(int)((m * 16 + 255) / 256), 256, 0, s>>>(bp, m, metric, w.s, w.t, nullptr);
-  k_row_terms<<<(int)((n * 16 + 255) / 256), 256, 0, s>>>(ap, n, metric, nullptr, nullptr, w.a_term);
+  const int64_t padded_m = (m + kTileB - 1) / kTileB * kTileB;
+  k_row_terms<<<(int)((padded_m * 16 + 255) / 256), 256, 0, s>>>(bp, m, padded_m, metric, w.s, w.t, nullptr);
+  k_row_terms<<<(int)((n * 16 + 255) / 256), 256, 0, s>>>(ap, n, n, metric, nullptr, nullptr, w.a_term);
   PairArgs p{};
   p.a = ap;
   p.b = bp;
@@ -403,8 +414,9 @@ int launch_pairwise_dense(const void* a, int64_t n, const void* b, int64_t m,
   float* at = w.a_term;
   const f16* ap = (const f16*)a;
   const f16* bp = (const f16*)b;
-  k_row_terms<<<(int)((m * 16 + 255) / 256), 256, 0, s>>>(bp, m, metric, sv, tv, nullptr);
-  k_row_terms<<<(int)((n * 16 + 255) / 256), 256, 0, s>>>(ap, n, metric, nullptr, nullptr, at);
+  const int64_t padded_m = (m + kTileB - 1) / kTileB * kTileB;
+  k_row_terms<<<(int)((padded_m * 16 + 255) / 256), 256, 0, s>>>(bp, m, padded_m, metric, sv, tv, nullptr);
+  k_row_terms<<<(int)((n * 16 + 255) / 256), 256, 0, s>>>(ap, n, n, metric, nullptr, nullptr, at);
   PairArgs p{};
   p.a = ap;
   p.b = bp;
