@@ -163,24 +163,40 @@ __global__ __launch_bounds__(kThreads, 2) void k_pairwise(const PairArgs p) {
     const int64_t ex_lo = a0 + p.exclude_offset, ex_hi = ex_lo + kBlockA;
     const bool may_exclude = p.exclude_offset >= 0 && ex_lo < j0 + kTileB && ex_hi > j0;
 
+    // the wave's 64 x 64 block of this tile: four independent accumulator chains (a
+    // 32x32x16 MFMA that reads the previous one's result stalls the issue port; two chains
+    // per wave left 46 % of the wave cycles in that stall), b operands read one k-step ahead
+    f32x16 acc4[2][2];   // [bt][at]
 #pragma unroll
-    for (int bt = 0; bt < 2; ++bt) {
-      // one 32-row b-tile at a time: 2 accumulators live
-      f32x16 accs[2];
+    for (int bt = 0; bt < 2; ++bt)
 #pragma unroll
       for (int at = 0; at < 2; ++at)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) accs[at][q] = 0.f;
-      f16x8 bf[8];   // all operand reads of the 32-row b-tile before the first MFMA
+        for (int q = 0; q < 16; ++q) acc4[bt][at][q] = 0.f;
+    {
+      f16x8 bf[2][2];   // [parity of ks][bt]
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks)
-        bf[ks] = *reinterpret_cast<const f16x8*>(tile + off256(64 * wb + 32 * bt + r, 2 * ks + hq));
-      __builtin_amdgcn_sched_barrier(0);
+      for (int bt = 0; bt < 2; ++bt)
+        bf[0][bt] = *reinterpret_cast<const f16x8*>(tile + off256(64 * wb + 32 * bt + r, hq));
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        accs[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ks], af[0][ks], accs[0], 0, 0, 0);
-        accs[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ks], af[1][ks], accs[1], 0, 0, 0);
+        if (ks < 7) {
+#pragma unroll
+          for (int bt = 0; bt < 2; ++bt)
+            bf[(ks + 1) & 1][bt] = *reinterpret_cast<const f16x8*>(
+                tile + off256(64 * wb + 32 * bt + r, 2 * (ks + 1) + hq));
+        }
+#pragma unroll
+        for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+          for (int at = 0; at < 2; ++at)
+            acc4[bt][at] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ks & 1][bt], af[at][ks],
+                                                                  acc4[bt][at], 0, 0, 0);
       }
+    }
+#pragma unroll
+    for (int bt = 0; bt < 2; ++bt) {
+      f32x16(&accs)[2] = acc4[bt];
       if constexpr (kDense) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
