@@ -444,3 +444,71 @@ def test_fused_head_equals_standalone_head(gpu_encoder, monkeypatch):
         as_f32 = np.concatenate(gpu_encoder.encode_graphs(shard, embedding_dtype=np.float32))
         monkeypatch.delenv("GFY_SEPARATE_HEAD")
         assert _maxabs(as_f32, fused) <= 6e-4    # one fp16 rounding of a unit-norm row
+
+
+def _plan_boundary_shard():
+    """One record whose 32-node tiles sit exactly on the limits of the layer kernel's tile
+    plans (csrc/gine_layer.inc): 8 in-edge slots per node, 96 far (out-of-tile) source rows
+    per tile; one over either limit must take the direct path and give the same numbers."""
+    from ginfinity_amd import GraphShard, GraphSpec
+    nodes = 32 * 6 + 7                      # ragged last tile
+    rng = np.random.default_rng(11)
+    src, dst = [], []
+
+    def far_sources(tile, count):           # distinct nodes outside `tile`
+        pool = np.setdiff1d(np.arange(nodes), np.arange(32 * tile, 32 * tile + 32))
+        return rng.choice(pool, size=count, replace=False)
+
+    for s in far_sources(0, 8):             # tile 0: node 3 has in-degree exactly 8 (staged)
+        src.append(s), dst.append(3)
+    for s in far_sources(1, 9):             # tile 1: node 40 has in-degree 9 (direct path)
+        src.append(s), dst.append(40)
+    for k, s in enumerate(far_sources(2, 96)):   # tile 2: exactly 96 far rows, 3 per node
+        src.append(s), dst.append(64 + k // 3)
+    for k, s in enumerate(far_sources(3, 97)):   # tile 3: 97 far rows (direct path)
+        src.append(s), dst.append(96 + k % 32)
+    for i in range(128, nodes):             # tiles 4-6: self loops, in-tile and backbone edges
+        src.append(i), dst.append(i)
+        if i + 1 < nodes:
+            src.append(i + 1), dst.append(i)
+            src.append(i), dst.append(i + 1)
+    for i in range(160, 192):               # the same far source for a whole tile, twice each
+        src += [5, 5]
+        dst += [i, i]
+    edge_index = np.array([src, dst], np.int32)
+    order = rng.permutation(edge_index.shape[1])
+    edge_index = np.ascontiguousarray(edge_index[:, order])
+    return GraphShard(
+        identifiers=("plans",), sequences=("A" * nodes,), structures=("." * nodes,),
+        node_features=rng.standard_normal((nodes, 7)).astype(np.float32),
+        edge_index=edge_index,
+        edge_types=rng.integers(0, 10, edge_index.shape[1]).astype(np.uint8),
+        node_ptr=np.array([0, nodes], np.int64),
+        edge_ptr=np.array([0, edge_index.shape[1]], np.int64), spec=GraphSpec.bundled(),
+        residue_index=np.arange(nodes, dtype=np.int32),
+        node_roles=(rng.random(nodes) < 0.2).astype(np.uint8) * np.uint8(1))
+
+
+def test_tile_plan_limits_against_oracle(gpu_encoder, oracle_weights):
+    from oracle import gine_numpy as G
+    shard = _plan_boundary_shard()
+    shard.node_roles[0] = 0                 # a record keeps at least one core node
+    got = np.concatenate(gpu_encoder.encode_graphs(shard))
+    want = G.encode(oracle_weights, shard.node_features, shard.edge_index, shard.edge_types)
+    core = shard.node_roles == 0
+    assert got.shape == (int(core.sum()), 128)
+    assert _maxabs(got, want[core]) <= F16_TOL
+    # hidden states after layers 1 and 4: every tile path (staged at the limits, direct)
+    trace = {}
+    G.forward_f16(oracle_weights.half(), shard.node_features, shard.edge_index,
+                  shard.edge_types, trace)
+    engine = gpu_encoder._engine
+    x, ei, et = _device_inputs(gpu_encoder, shard)
+    csr = engine.build_csr(ei, et, shard.node_count)
+    for stage in (1, 4):
+        h = engine.hidden(x, csr, stage).cpu().numpy()
+        ref = trace[f"l{stage - 1}.h"]
+        assert np.isfinite(h.astype(np.float32)).all()
+        # one-ulp accumulation-order flips only (they compound through the layers)
+        assert float(np.mean(h != ref)) < (0.05 if stage == 1 else 0.45), stage
+        assert _maxabs(h, ref) < 0.06, stage
