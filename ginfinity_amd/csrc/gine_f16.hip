@@ -182,6 +182,31 @@ __device__ __forceinline__ f16 f64_to_f16_rne(double x) {
   return (f16)f;
 }
 
+// fp16(o * inv) for eight values with the SAME result as rounding the float64 product once:
+// the fp32 product o * (float)inv is within 2 fp32 ulps of the float64 value, so both round
+// to the same fp16 unless the fp32 value lies within a few ulps of a rounding tie (the 13
+// dropped mantissa bits ~ 0x1000) or in fp16's subnormal range.  Only then (a fraction of
+// a percent of the rows) is the float64 path taken; it used to be 40 % of the vector
+// instructions of the head pass.
+__device__ __forceinline__ f16x8 scale_to_f16(const f16x8 o8, double inv) {
+  const float invf = (float)inv;
+  f16x8 out;
+  bool slow = false;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float q = (float)o8[j] * invf;
+    const uint32_t bits = __float_as_uint(q);
+    slow |= ((bits & 0x1FFFu) - 0xFFCu) <= 8u;               // within 4 fp32 ulps of a tie
+    slow |= ((bits & 0x7FFFFFFFu) - 1u) < 0x387FFFFFu;       // 0 < |q| < 2^-14
+    out[j] = (f16)q;
+  }
+  if (slow) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[j] = f64_to_f16_rne((double)(float)o8[j] * inv);
+  }
+  return out;
+}
+
 template <typename OutT>
 __device__ __forceinline__ void store8(OutT* dst, const double (&v)[8]);
 template <>
@@ -330,6 +355,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_head_f16(
           // one division, eight multiplies: differs from the exact quotient by <= 1 ulp of
           // float64, invisible after the single rounding to fp16 / fp32
           const double inv = 1.0 / den;
+          if constexpr (sizeof(OutT) == 2) {
+            if (node < n) {
+              const int dest = out_rows ? out_rows[node] : node;
+              if (dest >= 0)
+                *reinterpret_cast<f16x8*>(out + (size_t)dest * kOutDim + chunk * 8) =
+                    scale_to_f16(o8, inv);
+            }
+            continue;
+          }
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = v[j] * inv;
         }

@@ -512,3 +512,23 @@ def test_tile_plan_limits_against_oracle(gpu_encoder, oracle_weights):
         # one-ulp accumulation-order flips only (they compound through the layers)
         assert float(np.mean(h != ref)) < (0.05 if stage == 1 else 0.45), stage
         assert _maxabs(h, ref) < 0.06, stage
+
+
+def test_normalise_is_the_float64_quotient_rounded_once(gpu_encoder, monkeypatch):
+    """api.py:250-259: o / max(|o|, 1e-12) in float64, ONE rounding to fp16.  The kernels
+    take an fp32 shortcut wherever it provably rounds the same way; check all 7.7 M
+    values of a config-3 shard bit for bit, fused and stand-alone head."""
+    from ginfinity_amd import synthetic
+    shard = synthetic.roofline_shard(2)
+    engine = gpu_encoder._engine
+    x, ei, et = _device_inputs(gpu_encoder, shard)
+    csr = engine.build_csr(ei, et, shard.node_count)
+    raw = engine.encode(x, csr, normalise=False).cpu().numpy()
+    wide = raw.astype(np.float64)
+    norm = np.maximum(np.sqrt((wide * wide).sum(axis=1, keepdims=True)), 1e-12)
+    want = (wide / norm).astype(np.float16)
+    for separate in (False, True):
+        if separate:
+            monkeypatch.setenv("GFY_SEPARATE_HEAD", "1")
+        got = engine.encode(x, csr, normalise=True).cpu().numpy()
+        assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), separate
