@@ -1,0 +1,14 @@
+#!/bin/bash
+# Build the stand-alone measurement / probe programs (gfx950).  Run after
+# `python -m ginfinity_amd.build` (and `--stamps` for the diagnostic library); the
+# binaries are git-ignored but travel to the GPU box with the gpurun snapshot.
+set -e
+cd "$(dirname "$0")/.."
+RP='-Wl,-rpath,$ORIGIN/../ginfinity_amd/csrc'
+hipcc -O2 tools/gfy_bench.cpp -Iinclude -Lginfinity_amd/csrc -lgfy "$RP" -o tools/gfy_bench
+if [ -f ginfinity_amd/csrc/libgfy_stamps.so ]; then
+  hipcc -O2 -DGFY_STAMPS tools/gfy_bench.cpp -Iinclude -Lginfinity_amd/csrc -lgfy_stamps "$RP" -o tools/gfy_bench_stamps
+fi
+for p in clockcheck probe dma_probe coherence_probe; do
+  hipcc -O3 --offload-arch=gfx950 tools/$p.hip -o tools/$p
+done

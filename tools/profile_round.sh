@@ -1,5 +1,6 @@
 #!/bin/bash
 # Reproduce the committed measurement set of a round on a GPU box:
+#   python -m ginfinity_amd.build && python -m ginfinity_amd.build --stamps && bash tools/build_tools.sh
 #   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/profile_round.sh r01c'
 # Writes gpurun_out/<tag>/…; the summaries judged are then copied into profiles/.
 set -o pipefail
