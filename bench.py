@@ -16,7 +16,7 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   roofline      dominant kernel (k_gine_layer_f16): algorithmic bytes per launch
                 (512·N + 9·E + layer weights) ÷ its mean
                 duration (layers 1-3: the launches without the fused head) measured
-                with HIP events on the launch stream
+                with one HIP event pair around those three launches on the launch stream
   cpu_baseline  oracle/gine_torch.py (the reference's aten op sequence) timed on
                 this box's host cores on the same workload — N=1 only.
 """
@@ -159,7 +159,7 @@ def main() -> None:
     roofline = None
     kernels = None
     if rank == 0:
-        engine.set_timing(True)
+        engine.set_timing(2)      # no events between the layer launches that are averaged
         rounds = min(args.steps, 50)
         sums = None
         csr_ms = 0.0

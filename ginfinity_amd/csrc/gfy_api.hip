@@ -354,7 +354,7 @@ int gfy_encoder_set_timing(gfy_encoder* enc, int enable) {
     GFY_CHECK_HIP(hipSetDevice(enc->device));
     for (auto& ev : enc->events) GFY_CHECK_HIP(hipEventCreate(&ev));
   }
-  enc->timing = enable != 0;
+  enc->timing = enable == 2 ? 2 : enable != 0;
   enc->events_recorded = 0;
   return GFY_OK;
 }
@@ -368,8 +368,18 @@ int gfy_encoder_get_timing(gfy_encoder* enc, float* ms_host, int capacity, int* 
   GFY_REQUIRE(capacity >= spans, GFY_ERR_INVALID,
               "gfy_encoder_get_timing: capacity %d < %d", capacity, spans);
   GFY_CHECK_HIP(hipEventSynchronize(enc->events[spans]));
-  for (int i = 0; i < spans; ++i)
+  const int L = enc->layers;
+  for (int i = 0; i < spans; ++i) {
+    if (enc->timing == 2 && i >= 1 && i < L) {   // layers 1 .. L-1: one span, reported as its mean
+      if (i == 1) {
+        float block = 0.f;
+        GFY_CHECK_HIP(hipEventElapsedTime(&block, enc->events[1], enc->events[L]));
+        for (int k = 1; k < L; ++k) ms_host[k] = block / (float)(L - 1);
+      }
+      continue;
+    }
     GFY_CHECK_HIP(hipEventElapsedTime(&ms_host[i], enc->events[i], enc->events[i + 1]));
+  }
   *count = spans;
   return GFY_OK;
 }

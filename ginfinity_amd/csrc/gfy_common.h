@@ -112,14 +112,18 @@ struct gfy_encoder {
   gfy::ModelF16 f16{};
   gfy::ModelF32 f32{};
   // optional per-kernel timing (gfy_encoder_set_timing)
-  bool timing = false;
+  // slot 0 before the setup launch, 1 after it, 1 + l after layer launch l, layers + 2
+  // after the stand-alone head.  Mode 2 leaves out the events between layer launches
+  // 1 .. layers-1: an event between two dependent kernels costs ~2.5 us of stream time that
+  // rocprof's kernel durations do not contain.
+  int timing = 0;
   hipEvent_t events[gfy::kMaxLayers + 3] = {};
   mutable int events_recorded = 0;
   void mark(hipStream_t s, int slot) const {
-    if (timing) {
-      (void)hipEventRecord(events[slot], s);
-      events_recorded = slot + 1;
-    }
+    if (!timing) return;
+    if (timing == 2 && slot >= 2 && slot < layers) return;
+    (void)hipEventRecord(events[slot], s);
+    events_recorded = slot + 1;
   }
 };
 

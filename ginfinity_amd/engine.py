@@ -164,9 +164,11 @@ class DeviceEncoder:
         return out
 
     # -- diagnostics -------------------------------------------------------------------
-    def set_timing(self, enabled: bool) -> None:
+    def set_timing(self, enabled: bool | int) -> None:
+        """True / 1: an event after every launch; 2: none between layer launches
+        1 .. L-1, whose mean is reported (agrees with rocprof's kernel durations)."""
         native.check(self._lib.gfy_encoder_set_timing(
-            self._handle, 1 if enabled else 0), "gfy_encoder_set_timing")
+            self._handle, int(enabled)), "gfy_encoder_set_timing")
 
     def kernel_times_ms(self) -> list[float]:
         """Device time between the marks of the last ``encode`` (timing enabled):

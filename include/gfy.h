@@ -128,7 +128,10 @@ int gfy_encode_hidden(gfy_encoder* encoder, const float* node_features,
 
 /* Per-kernel device timing of gfy_encode (diagnostics; bench.py's roofline
  * figure).  While enabled, gfy_encode brackets each kernel with hipEvents on the
- * caller's stream (do not enable under graph capture).  gfy_encoder_get_timing
+ * caller's stream (do not enable under graph capture).  enable = 2 leaves out the
+ * events BETWEEN layer launches 1 .. layers-1 and reports their mean: an event between
+ * two dependent kernels adds ~2.5 us of stream time that a profiler's kernel duration
+ * does not contain.  gfy_encoder_get_timing
  * waits for the last gfy_encode and writes milliseconds to ms_host:
  * [0] per-encode setup (tile plans + input Linear), [1..layers] GINE layer
  * launches, [layers+1] stand-alone head+normalise (fp16-model fp16 output: the
