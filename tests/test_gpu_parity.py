@@ -176,6 +176,16 @@ def test_microbatch_layout_does_not_change_results(gpu_encoder, rouskin_shard):
     np.testing.assert_array_equal(whole, small)
 
 
+def test_one_micro_batch_of_900k_nodes_equals_fifteen(gpu_encoder, rouskin_shard):
+    """~55 tiles per workgroup instead of ~4 (plan ring, look-ahead and the fused head pass
+    run many times around) must give the bytes the default 60k-node micro-batches give."""
+    default = np.concatenate(gpu_encoder.encode_graphs(rouskin_shard))
+    single = np.concatenate(gpu_encoder.encode_graphs(
+        rouskin_shard, max_batch_nodes=1_000_000, max_batch_edges=5_000_000))
+    assert default.shape == (rouskin_shard.node_count, 128)
+    np.testing.assert_array_equal(default, single)
+
+
 def test_synthetic_roofline_shard_config3(gpu_encoder, golden):
     from ginfinity_amd import synthetic
     g = golden("synthetic.npz")
