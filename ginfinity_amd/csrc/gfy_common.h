@@ -172,7 +172,7 @@ __device__ __forceinline__ void dma16(const void* gbase /* uniform */, uint32_t 
       "s_nop 0\n\t"
       "global_load_lds_dwordx4 %1, %2"
       :
-      : "s"(lds), "v"(goff), "s"(gbase)
+      : "s"(__builtin_amdgcn_readfirstlane(lds)), "v"(goff), "s"(gbase)
       : "memory");
 }
 __device__ __forceinline__ void dma16_at(const void* lane_ptr, uint32_t lds) {   // 64-bit form
@@ -181,7 +181,7 @@ __device__ __forceinline__ void dma16_at(const void* lane_ptr, uint32_t lds) {  
       "s_nop 0\n\t"
       "global_load_lds_dwordx4 %1, off"
       :
-      : "s"(lds), "v"(lane_ptr)
+      : "s"(__builtin_amdgcn_readfirstlane(lds)), "v"(lane_ptr)
       : "memory");
 }
 // The builtin (not an asm string) so that hipcc's own waitcnt bookkeeping learns that
