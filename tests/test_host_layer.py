@@ -118,6 +118,35 @@ def test_whole_rouskin_shard_hashes_match_reference_builder(golden, rouskin_shar
     piece.validate_values()
 
 
+def test_whole_shard_builder_equals_per_record_builder(rouskin_records):
+    """build_shard builds unsliced records in one pass of whole-shard array operations; the
+    arrays must be bit-identical to concatenating per-record graphs (which the reference
+    fixtures pin), for every length / nesting corner and for both struct features."""
+    from ginfinity_amd import GraphShard
+    corner = [RNA("one", "A", "."), RNA("two", "AC", ".."), RNA("three", "ACG", "..."),
+              RNA("pair2", "GC", "()"), RNA("stack", "GGGGAAAACCCC", "((((....))))"),
+              RNA("twostems", "GGAACCGGAACC", "((..))((..))"),
+              RNA("nested", "GGGAAACCCAAAGGGAAACCC", "(((...)))...(((...)))"),
+              RNA("deep", "G" * 40 + "AAAA" + "C" * 40, "(" * 40 + "...." + ")" * 40)]
+    again = [RNA(r.identifier + "-again", r.sequence, r.structure) for r in corner[::-1]]
+    records = corner + list(rouskin_records[:300]) + again
+    for spec in (GraphSpec.bundled(),):
+        builder = GraphBuilder(spec)
+        whole = builder.build_shard(records)
+        parts = GraphShard.from_graphs(builder.build_many(records))
+        assert whole.identifiers == parts.identifiers
+        assert whole.sequences == parts.sequences and whole.structures == parts.structures
+        for name in ("node_features", "edge_index", "edge_types", "node_ptr", "edge_ptr",
+                     "residue_index", "node_roles"):
+            a, b = getattr(whole, name), getattr(parts, name)
+            assert a.dtype == b.dtype and a.shape == b.shape, name
+            assert a.tobytes() == b.tobytes(), name
+    # a sliced record anywhere sends the whole call down the per-record path
+    mixed = [RNA("w", "GGGAAACCCUUUUGGG", "(((...))).......", start=9, end=16)] + corner
+    shard = GraphBuilder(keep_paired_neighbours=True).build_shard(mixed)
+    assert shard.record_count == len(mixed) and shard.node_roles.max() <= 1
+
+
 def test_sliced_graphs_match_reference(golden):
     g = golden("sliced.npz")
     for hops in (1, 2, 3):
