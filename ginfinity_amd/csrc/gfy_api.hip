@@ -359,6 +359,16 @@ int gfy_encoder_set_timing(gfy_encoder* enc, int enable) {
   return GFY_OK;
 }
 
+int gfy_encoder_set_layer_workgroups(gfy_encoder* enc, int workgroups) {
+  clear_error();
+  GFY_REQUIRE(enc != nullptr, GFY_ERR_INVALID,
+              "gfy_encoder_set_layer_workgroups: encoder is NULL");
+  GFY_REQUIRE(workgroups >= 0 && workgroups <= 65536, GFY_ERR_INVALID,
+              "gfy_encoder_set_layer_workgroups: %d outside 0..65536", workgroups);
+  enc->layer_workgroups = workgroups;
+  return GFY_OK;
+}
+
 int gfy_encoder_get_timing(gfy_encoder* enc, float* ms_host, int capacity, int* count) {
   clear_error();
   GFY_REQUIRE(enc && ms_host && count, GFY_ERR_INVALID, "gfy_encoder_get_timing: NULL argument");

@@ -116,6 +116,7 @@ struct gfy_encoder {
   // after the stand-alone head.  Mode 2 leaves out the events between layer launches
   // 1 .. layers-1: an event between two dependent kernels costs ~2.5 us of stream time that
   // rocprof's kernel durations do not contain.
+  int layer_workgroups = 0;   // gfy_encoder_set_layer_workgroups (0 = default)
   int timing = 0;
   hipEvent_t events[gfy::kMaxLayers + 3] = {};
   mutable int events_recorded = 0;

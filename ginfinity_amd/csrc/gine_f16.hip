@@ -445,9 +445,10 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
   const int num_tiles = (int)((n + kTile - 1) / kTile);   // stand-alone head kernel
   const int grid = persistent_grid(num_tiles);
   const int layer_tiles = (int)((n + kT2 - 1) / kT2);
-  int layer_grid = layer_tiles < 512 ? layer_tiles : 512;   // two 256-thread workgroups per CU
+  int layer_cap = enc->layer_workgroups > 0 ? enc->layer_workgroups : 512;   // 512 = two per CU
+  if (const char* g = getenv("GFY_LAYER_GRID")) layer_cap = atoi(g);          // diagnostic
+  int layer_grid = layer_tiles < layer_cap ? layer_tiles : layer_cap;
   layer_grid = (layer_grid + 7) & ~7;                        // whole XCD rounds
-  if (const char* g = getenv("GFY_LAYER_GRID")) layer_grid = atoi(g);   // diagnostic
 
   const int64_t items = n * 16;
   enc->mark(s, 0);

@@ -164,6 +164,12 @@ class DeviceEncoder:
         return out
 
     # -- diagnostics -------------------------------------------------------------------
+    def set_layer_workgroups(self, workgroups: int) -> None:
+        """Cap the layer kernel's grid (0 = default 512).  256 gives more nodes/s when
+        several encodes are in flight on different streams (include/gfy.h)."""
+        native.check(self._lib.gfy_encoder_set_layer_workgroups(
+            self._handle, int(workgroups)), "gfy_encoder_set_layer_workgroups")
+
     def set_timing(self, enabled: bool | int) -> None:
         """True / 1: an event after every launch; 2: none between layer launches
         1 .. L-1, whose mean is reported (agrees with rocprof's kernel durations)."""

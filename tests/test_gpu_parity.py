@@ -542,3 +542,20 @@ def test_normalise_is_the_float64_quotient_rounded_once(gpu_encoder, monkeypatch
             monkeypatch.setenv("GFY_SEPARATE_HEAD", "1")
         got = engine.encode(x, csr, normalise=True).cpu().numpy()
         assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), separate
+
+
+def test_layer_workgroup_cap_does_not_change_results(gpu_encoder):
+    """gfy_encoder_set_layer_workgroups is a scheduling knob: 8, 256 and the default 512
+    workgroups must give the same bytes (more tiles per workgroup, other tile -> XCD map)."""
+    from ginfinity_amd import synthetic
+    shard = synthetic.roofline_shard(4, records=3, length=2000)
+    engine = gpu_encoder._engine
+    x, ei, et = _device_inputs(gpu_encoder, shard)
+    csr = engine.build_csr(ei, et, shard.node_count)
+    default = engine.encode(x, csr).cpu().numpy()
+    try:
+        for cap in (8, 256):
+            engine.set_layer_workgroups(cap)
+            np.testing.assert_array_equal(engine.encode(x, csr).cpu().numpy(), default)
+    finally:
+        engine.set_layer_workgroups(0)

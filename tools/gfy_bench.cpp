@@ -96,7 +96,8 @@ int main(int argc, char** argv) {
   CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
   CK(hipEventElapsedTime(&ms, e0, e1));
   printf("encode only: %.1f us/step\n", 1e3 * ms / steps);
-  for (int lanes = 2; lanes <= 4; ++lanes) {  // independent shards in flight on several streams
+  const int max_lanes = getenv("GFY_BENCH_STREAMS") ? atoi(getenv("GFY_BENCH_STREAMS")) : 4;
+  for (int lanes = 2; lanes <= max_lanes; lanes += lanes < 4 ? 1 : 2) {  // independent shards in flight on several streams
     std::vector<gfy_encoder*> encs(lanes); std::vector<hipStream_t> ss(lanes);
     std::vector<int32_t*> rp(lanes), cl(lanes); std::vector<uint8_t*> ty(lanes);
     std::vector<void*> outs(lanes), wa(lanes), wb(lanes);
