@@ -142,11 +142,11 @@ int gfy_encoder_set_timing(gfy_encoder* encoder, int enable);
 /* Throughput tuning (no reference counterpart).  The fused layer kernel is launched with
  * at most `workgroups` 256-thread workgroups (0 = default: 512, two per CU, the fastest
  * for one encode at a time).  A caller that keeps several encodes in flight on different
- * streams AND enqueues fast enough to keep two layer launches runnable at all times gets
- * ~4 % more nodes/s with 256 (two launches share every CU instead of taking turns, the
- * prologue of one runs under the tiles of the other: tools/gfy_bench, 4 streams, 631 ->
- * 656 M nodes/s); a slower host loses (bench.py: 554 -> 518 M nodes/s), so bench.py keeps
- * the default.  Rounded up to a multiple of 8; results do not depend on it. */
+ * streams — each on its own hardware queue, see GPU_MAX_HW_QUEUES in bench.py — gets ~5 %
+ * more nodes/s with 256: two layer launches then share every CU instead of taking turns,
+ * and the prologue of one runs under the tiles of the other (bench.py, 4 streams: 645 ->
+ * 678 M nodes/s; one encode at a time loses: 146 -> 183 us).  Rounded up to a multiple
+ * of 8; results do not depend on it. */
 int gfy_encoder_set_layer_workgroups(gfy_encoder* encoder, int workgroups);
 int gfy_encoder_get_timing(gfy_encoder* encoder, float* ms_host, int capacity,
                            int* count);

@@ -11,13 +11,13 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 
 # 1. bench lines (default = 4 shards in flight; one shard at a time)
-timeout -k 10 300 python3 $R/bench.py --steps 400 --warmup 40 > $OUT/bench_line.json 2> $OUT/bench_line.err || exit 1
-timeout -k 10 200 python3 $R/bench.py --steps 400 --warmup 40 --streams 1 --no-cpu-baseline > $OUT/bench_1stream_line.json 2>> $OUT/bench_line.err || exit 1
+timeout -k 10 300 python3 $R/bench.py --steps 1000 --warmup 100 > $OUT/bench_line.json 2> $OUT/bench_line.err || exit 1
+timeout -k 10 200 python3 $R/bench.py --steps 1000 --warmup 100 --streams 1 --no-cpu-baseline > $OUT/bench_1stream_line.json 2>> $OUT/bench_line.err || exit 1
 
 # 2. per-kernel durations of the same command (kernel trace + stats only)
 for S in 1 4; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/kt$S -o kt --output-format csv -- \
-    python3 $R/bench.py --steps 400 --warmup 40 --streams $S --no-cpu-baseline > $OUT/bench_${S}stream_line_profiled.json 2> $OUT/kt$S.err || exit 1
+    python3 $R/bench.py --steps 1000 --warmup 100 --streams $S --no-cpu-baseline > $OUT/bench_${S}stream_line_profiled.json 2> $OUT/kt$S.err || exit 1
 done
 
 # 3. HBM traffic counters: separate passes, kernel trace only (MI355X_MICROARCH.md, HBM section)
