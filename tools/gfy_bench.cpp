@@ -18,6 +18,7 @@ extern "C" int gfy_debug_real(unsigned long long*);
 #define GK(x) do { int s_ = (x); if (s_ != 0) { printf("gfy error %d: %s (line %d)\n", s_, gfy_last_error(), __LINE__); exit(1);} } while (0)
 
 int main(int argc, char** argv) {
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);   // one hardware queue per stream in flight (see bench.py)
   const int64_t N = argc > 1 ? atoll(argv[1]) : 60000;
   const int steps = argc > 2 ? atoi(argv[2]) : 200;
   const bool no_edges = argc > 3 && argv[3][0] == 'n';   // MLP-only timing
