@@ -151,8 +151,9 @@ class DeviceEncoder:
         """CSR build + encode of one device-resident shard as a pre-bound callable
         ``step(stream_handle)``: buffers, workspaces and pointers are resolved once, each
         call is two C-ABI calls and nothing else.  For steady-state loops over same-sized
-        shards (bench.py): per-step Python overhead drops from ~50 us to a few us, which
-        matters once the GPU needs ~100 us per step and four streams have to be fed."""
+        shards (bench.py): per-step Python overhead drops from ~50 us to a few us.  The
+        calling thread's current device must be this encoder's device (the C ABI launches on
+        the caller's device; ``torch.cuda.set_device`` once, as bench.py does)."""
         nodes = int(node_features.shape[0])
         edges = int(edge_types.numel())
         assert node_features.dtype == torch.float32 and node_features.is_contiguous()
