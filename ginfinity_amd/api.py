@@ -16,6 +16,8 @@ module.  Differences a user can observe, all deliberate:
 """
 from __future__ import annotations
 
+from concurrent.futures import ThreadPoolExecutor
+
 import json
 from pathlib import Path
 from typing import Sequence
@@ -79,6 +81,7 @@ class Ginfinity:
     def __init__(self, engine: DeviceEncoder, checkpoint: LoadedCheckpoint,
                  device: str, *, full_precision: bool) -> None:
         self._engine = engine
+        self._copier: ThreadPoolExecutor | None = None
         self._metadata = checkpoint.metadata
         self._config = checkpoint.config
         self._graph_spec = checkpoint.graph_spec
@@ -182,14 +185,40 @@ class Ginfinity:
         if shard is None:
             return []
         embedding_dtype = _embedding_dtype(embedding_dtype)
+        bounds = microbatch_bounds(shard.lengths, shard.edge_counts,
+                                   max_batch_nodes, max_batch_edges)
+        if len(bounds) == 1:
+            return self._run_graph_shard(shard, embedding_dtype)
+        # Several micro-batches: the copy of batch k back to the host (15 MB, the long pole:
+        # the kernels take 0.15 ms) runs on a helper thread while this thread slices,
+        # uploads and launches batch k+1 — PCIe is full duplex.  Compute stays on ONE
+        # stream in batch order (one encoder, one workspace).
+        torch_dtype, _code, exact = device_output_dtype(embedding_dtype)
+        if self._copier is None:
+            self._copier = ThreadPoolExecutor(max_workers=1,
+                                              thread_name_prefix="ginfinity-d2h")
+        pending = []
+        for start, stop in bounds:
+            piece = shard.slice(start, stop)
+            block = self._encode_shard_device(piece, torch_dtype)
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(block.device))
+            pending.append(self._copier.submit(
+                self._download, block, ready, piece.core_counts, embedding_dtype, exact))
         outputs: list[np.ndarray] = []
-        for start, stop in microbatch_bounds(
-                shard.lengths, shard.edge_counts,
-                max_batch_nodes, max_batch_edges):
-            piece = (shard if (start, stop) == (0, shard.record_count)
-                     else shard.slice(start, stop))
-            outputs.extend(self._run_graph_shard(piece, embedding_dtype))
+        for job in pending:
+            outputs.extend(job.result())
         return outputs
+
+    @staticmethod
+    def _download(block: torch.Tensor, ready: "torch.cuda.Event", core_counts,
+                  embedding_dtype: np.dtype, exact: bool) -> list[np.ndarray]:
+        ready.synchronize()
+        with torch.cuda.device(block.device):
+            host = block.cpu().numpy()
+        if not exact:
+            host = host.astype(embedding_dtype)
+        return np.split(host, np.cumsum(core_counts)[:-1], axis=0)
 
     # -- the seam (reference: api.py:232-260) -----------------------------------------
     def _encode_shard_device(self, shard: GraphShard, out_dtype: torch.dtype
