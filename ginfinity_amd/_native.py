@@ -26,6 +26,9 @@ SIGNATURES: dict[str, tuple] = {
     "gfy_encoder_create": (c_int, [c_void_p, c_size_t, c_int, c_int,
                                    POINTER(c_void_p)]),
     "gfy_encoder_destroy": (None, [c_void_p]),
+    "gfy_build_graphs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                 c_int64, c_int64, c_int, c_int, c_int, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gfy_csr_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "gfy_build_csr": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p,
                               c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -26,9 +26,10 @@ import numpy as np
 import torch
 
 from .engine import DeviceEncoder, device_output_dtype
-from .graph import Graph, GraphBuilder, GraphShard
+from .graph import Graph, GraphBuilder, GraphShard, shard_text
 from .records import RNA
-from .spec import DATA_DIRECTORY, GraphCompatibilityError, GraphSpec
+from .spec import (DATA_DIRECTORY, GraphCompatibilityError, GraphSpec,
+                   GraphValidationError)
 from .weights import LoadedCheckpoint, ModelIntegrityError, load_checkpoint
 
 
@@ -82,6 +83,7 @@ class Ginfinity:
                  device: str, *, full_precision: bool) -> None:
         self._engine = engine
         self._copier: ThreadPoolExecutor | None = None
+        self._preparer: ThreadPoolExecutor | None = None
         self._metadata = checkpoint.metadata
         self._config = checkpoint.config
         self._graph_spec = checkpoint.graph_spec
@@ -142,12 +144,73 @@ class Ginfinity:
         records = list(records)
         if not records:
             return []
+        if not any(record.sliced for record in records):
+            return self._encode_records(records, max_batch_nodes, max_batch_edges,
+                                        _embedding_dtype(embedding_dtype))
         shard = GraphBuilder(
             self._graph_spec, keep_paired_neighbours=keep_paired_neighbours,
             context_hops=context_hops).build_shard(records)
         return self.encode_graphs(
             shard, max_batch_nodes=max_batch_nodes,
             max_batch_edges=max_batch_edges, embedding_dtype=embedding_dtype)
+
+    def _encode_records(self, records: Sequence[RNA], max_batch_nodes: int,
+                        max_batch_edges: int, embedding_dtype: np.dtype
+                        ) -> list[np.ndarray]:
+        """Unsliced records: the graphs are built ON THE DEVICE (``gfy_build_graphs``,
+        the arrays ``GraphBuilder`` would produce, bit for bit) — only the text, the
+        record offsets and the positional columns cross PCIe, 2 + 8 bytes per nucleotide
+        instead of 46.  Same packing, limits and errors as ``encode_graphs``."""
+        text = shard_text(records, self._graph_spec)
+        if max_batch_nodes <= 0 or max_batch_edges <= 0:
+            raise ValueError("batch node and edge limits must be positive")
+        lengths, edge_counts = text.lengths.tolist(), text.edge_counts.tolist()
+        if max(lengths) > max_batch_nodes:
+            raise ValueError("max_batch_nodes is smaller than the longest graph")
+        if max(edge_counts) > max_batch_edges:
+            raise ValueError("max_batch_edges is smaller than the largest graph")
+        torch_dtype, _code, exact = device_output_dtype(embedding_dtype)
+        engine, device = self._engine, self._engine.device
+        spec = self._graph_spec
+        if self._copier is None:
+            self._copier = ThreadPoolExecutor(max_workers=1,
+                                              thread_name_prefix="ginfinity-d2h")
+        pending, verdicts = [], []
+        bounds = microbatch_bounds(lengths, edge_counts, max_batch_nodes, max_batch_edges)
+        # the positional columns (numpy sin / cos, GIL released) of later micro-batches are
+        # computed on a second helper thread while this one uploads and launches
+        if self._preparer is None:
+            self._preparer = ThreadPoolExecutor(max_workers=1,
+                                                thread_name_prefix="ginfinity-prep")
+        columns_of = [self._preparer.submit(text.positional, a, b) for a, b in bounds]
+        for (start, stop), columns_job in zip(bounds, columns_of):
+            n0, n1 = int(text.node_ptr[start]), int(text.node_ptr[stop])
+            e0, e1 = int(text.edge_ptr[start]), int(text.edge_ptr[stop])
+            columns = columns_job.result()
+            upload = lambda array: torch.from_numpy(array).to(device)   # noqa: E731
+            features, edge_index, edge_types, first_invalid = engine.build_graphs(
+                upload(text.bases[n0:n1]), upload(text.marks[n0:n1]),
+                upload(text.node_ptr[start:stop + 1]), upload(text.edge_ptr[start:stop + 1]),
+                None if columns is None else upload(columns), n1 - n0, e1 - e0,
+                struct_states=1 if spec.struct_feature == "A" else 3,
+                skip2=spec.has_skip2)
+            csr = engine.build_csr(edge_index, edge_types, n1 - n0)
+            block = engine.encode(features, csr, out_dtype=torch_dtype, normalise=True)
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(device))
+            verdicts.append((start, first_invalid))
+            pending.append(self._copier.submit(
+                self._download, block, ready, lengths[start:stop], embedding_dtype, exact))
+        outputs: list[np.ndarray] = []
+        for job in pending:
+            outputs.extend(job.result())
+        for start, first_invalid in verdicts:
+            bad = int(first_invalid.item())
+            if bad >= 0:
+                raise GraphValidationError(
+                    f"record {records[start + bad].identifier!r}: sequence or structure "
+                    "text is not a balanced dot-bracket string over A, C, G, U")
+        return outputs
 
     def encode_graph(self, graph: Graph, *,
                      embedding_dtype: np.dtype | str = np.float16) -> np.ndarray:

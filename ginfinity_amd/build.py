@@ -16,8 +16,8 @@ from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIBRARY = CSRC / "libgfy.so"
-SOURCES = ("gfy_api.hip", "csr_build.hip", "gine_f16.hip", "gine_f32.hip",
-           "pairwise.hip")
+SOURCES = ("gfy_api.hip", "graph_build.hip", "csr_build.hip", "gine_f16.hip",
+           "gine_f32.hip", "pairwise.hip")
 ARCH = "gfx950"
 # -ffp-contract=off: the rounding-point contract needs mul and add to round
 # separately unless the source says fma.

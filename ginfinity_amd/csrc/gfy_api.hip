@@ -417,6 +417,32 @@ int gfy_build_csr(const int32_t* edge_index, const uint8_t* edge_types,
                           ws_bytes, (hipStream_t)stream);
 }
 
+int gfy_build_graphs(const uint8_t* bases, const uint8_t* marks, const int64_t* node_ptr,
+                     const int64_t* edge_ptr, int64_t records, int64_t n, int64_t e,
+                     int struct_states, int positional_columns, int skip2,
+                     const float* positional, float* node_features, int32_t* edge_index,
+                     uint8_t* edge_types, int32_t* first_invalid, void* stream) {
+  clear_error();
+  GFY_REQUIRE(records >= 0 && n >= 0 && n < INT32_MAX && e >= 0 && e < INT32_MAX,
+              GFY_ERR_INVALID, "gfy_build_graphs: records=%lld n=%lld e=%lld out of range",
+              (long long)records, (long long)n, (long long)e);
+  GFY_REQUIRE(struct_states == 1 || struct_states == 3, GFY_ERR_INVALID,
+              "gfy_build_graphs: struct_states must be 1 (paired flag) or 3 (one-hot)");
+  GFY_REQUIRE(positional_columns == 0 || positional_columns == 2, GFY_ERR_INVALID,
+              "gfy_build_graphs: positional_columns must be 0 or 2");
+  GFY_REQUIRE(node_ptr && edge_ptr && first_invalid, GFY_ERR_INVALID,
+              "gfy_build_graphs: NULL argument");
+  GFY_REQUIRE(n == 0 || (bases && marks && node_features), GFY_ERR_INVALID,
+              "gfy_build_graphs: NULL node array with N=%lld", (long long)n);
+  GFY_REQUIRE(n == 0 || positional_columns == 0 || positional, GFY_ERR_INVALID,
+              "gfy_build_graphs: positional columns requested but positional is NULL");
+  GFY_REQUIRE(e == 0 || (edge_index && edge_types), GFY_ERR_INVALID,
+              "gfy_build_graphs: NULL edge array with E=%lld", (long long)e);
+  return launch_build_graphs(bases, marks, node_ptr, edge_ptr, records, n, e, struct_states,
+                             positional_columns, skip2 ? 1 : 0, positional, node_features,
+                             edge_index, edge_types, first_invalid, (hipStream_t)stream);
+}
+
 size_t gfy_encode_workspace_bytes(const gfy_encoder* enc, int64_t n, int64_t e) {
   if (!enc) return 0;
   n = n < 1 ? 1 : n;

@@ -136,6 +136,12 @@ int launch_build_csr(const int32_t* edge_index, const uint8_t* edge_types,
                      uint8_t* typ, void* ws, size_t ws_bytes, hipStream_t s);
 size_t csr_workspace_bytes(int64_t n, int64_t e);
 
+int launch_build_graphs(const uint8_t* bases, const uint8_t* marks, const int64_t* node_ptr,
+                        const int64_t* edge_ptr, int64_t records, int64_t n, int64_t e,
+                        int struct_states, int positional_cols, int skip2,
+                        const float* positional, float* features, int32_t* edge_index,
+                        uint8_t* edge_types, int32_t* first_invalid, hipStream_t s);
+
 int launch_encode_f16(const gfy_encoder* enc, const float* x,
                       const int32_t* row_ptr, const int32_t* col,
                       const uint8_t* typ, int64_t n, int64_t e,

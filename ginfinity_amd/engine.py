@@ -120,6 +120,39 @@ class DeviceEncoder:
                 scratch.numel(), self._stream()), "gfy_build_csr")
         return DeviceCsr(row_ptr, col, typ, nodes, edges)
 
+    def build_graphs(self, bases: torch.Tensor, marks: torch.Tensor,
+                     node_ptr: torch.Tensor, edge_ptr: torch.Tensor,
+                     positional: torch.Tensor | None, nodes: int, edges: int, *,
+                     struct_states: int, skip2: bool
+                     ) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+        """Sequence / dot-bracket text of unsliced records (device uint8 [N] each, int64
+        [R+1] offsets) → (node_features f32 [N,F], edge_index int32 [2,E], edge_types uint8
+        [E], first_invalid int32 [1]) on the device: ``GraphBuilder._build_full`` for every
+        record (graph.py:494-561), bit-identical arrays.  ``first_invalid`` is -1 when every
+        record was a balanced structure consistent with ``edge_ptr``; read it after the
+        stream has run."""
+        records = int(node_ptr.numel()) - 1
+        columns = 0 if positional is None else int(positional.shape[1])
+        assert bases.dtype == torch.uint8 and marks.dtype == torch.uint8
+        assert int(bases.numel()) == nodes == int(marks.numel())
+        assert node_ptr.dtype == torch.int64 and edge_ptr.dtype == torch.int64
+        assert int(edge_ptr.numel()) == records + 1
+        assert positional is None or (positional.dtype == torch.float32
+                                      and positional.is_contiguous()
+                                      and positional.shape[0] == nodes)
+        with torch.cuda.device(self.device):
+            features = torch.empty((nodes, 4 + struct_states + columns),
+                                   dtype=torch.float32, device=self.device)
+            edge_index = torch.empty((2, edges), dtype=torch.int32, device=self.device)
+            edge_types = torch.empty(edges, dtype=torch.uint8, device=self.device)
+            first_invalid = torch.empty(1, dtype=torch.int32, device=self.device)
+            native.check(self._lib.gfy_build_graphs(
+                _ptr(bases), _ptr(marks), _ptr(node_ptr), _ptr(edge_ptr), records, nodes,
+                edges, struct_states, columns, 1 if skip2 else 0, _ptr(positional),
+                _ptr(features), _ptr(edge_index), _ptr(edge_types), _ptr(first_invalid),
+                self._stream()), "gfy_build_graphs")
+        return features, edge_index, edge_types, first_invalid
+
     def encode(self, node_features: torch.Tensor, csr: DeviceCsr, *,
                out_rows: torch.Tensor | None = None,
                n_out: int | None = None,

@@ -599,6 +599,73 @@ class GraphBuilder:
             node_roles=np.full(total, NODE_ROLE_CORE, dtype=np.uint8))
 
 
+@dataclass(frozen=True)
+class ShardText:
+    """Unsliced records in the form the device builder takes (``gfy_build_graphs``,
+    include/gfy.h): the concatenated sequence and dot-bracket bytes plus the node / edge
+    offsets of every record — everything the host can know without building a graph."""
+
+    bases: np.ndarray       # uint8 [N]
+    marks: np.ndarray       # uint8 [N]
+    node_ptr: np.ndarray    # int64 [R+1]
+    edge_ptr: np.ndarray    # int64 [R+1]
+    spec: GraphSpec
+
+    @property
+    def lengths(self) -> np.ndarray:
+        return np.diff(self.node_ptr)
+
+    @property
+    def edge_counts(self) -> np.ndarray:
+        return np.diff(self.edge_ptr)
+
+    def positional(self, start: int, stop: int) -> np.ndarray | None:
+        """float32 [nodes of records start..stop, 2]: sin / cos of the relative position,
+        the reference's numpy float32 expression (graph.py:508-513), or None."""
+        if not self.spec.positional:
+            return None
+        lengths = self.lengths[start:stop]
+        first = self.node_ptr[start]
+        nodes = int(self.node_ptr[stop] - first)
+        owner = np.repeat(np.arange(stop - start, dtype=np.int64), lengths)
+        position = np.arange(nodes, dtype=np.int64) - (self.node_ptr[start:stop] - first)[owner]
+        denominator = np.maximum(lengths - 1, 1).astype(np.float32)[owner]
+        angle = np.float32(np.pi) * (position.astype(np.float32) / denominator)
+        columns = np.empty((nodes, 2), dtype=np.float32)
+        np.sin(angle, out=columns[:, 0])
+        np.cos(angle, out=columns[:, 1])
+        return columns
+
+
+def shard_text(records: Sequence[RNA], spec: GraphSpec) -> ShardText:
+    """``ShardText`` of unsliced records.  The edge count of a record follows from its
+    length and its number of '(' (graph.py:516-546): 2(L-1) backbone + 2 pairs +
+    2 max(L-2, 0) skip-2 edges."""
+    if any(record.sliced for record in records):
+        raise ValueError("shard_text takes unsliced records only")
+    count = len(records)
+    if count == 0:
+        raise GraphValidationError("a graph shard cannot be empty")
+    if len({record.identifier for record in records}) != count:
+        raise GraphValidationError("duplicate identifiers in graph shard")
+    lengths = np.fromiter((r.length for r in records), dtype=np.int64, count=count)
+    pairs = np.fromiter((r.structure.count("(") for r in records), dtype=np.int64,
+                        count=count)
+    node_ptr = np.zeros(count + 1, dtype=np.int64)
+    np.cumsum(lengths, out=node_ptr[1:])
+    if int(node_ptr[-1]) > _INT32_MAX:
+        raise GraphValidationError(
+            "graph shard exceeds the int32 node-index capacity; split it")
+    per_record = 2 * np.maximum(lengths - 1, 0) + 2 * pairs
+    if spec.has_skip2:
+        per_record += 2 * np.maximum(lengths - 2, 0)
+    edge_ptr = np.zeros(count + 1, dtype=np.int64)
+    np.cumsum(per_record, out=edge_ptr[1:])
+    bases = np.frombuffer("".join(r.sequence for r in records).encode("ascii"), np.uint8)
+    marks = np.frombuffer("".join(r.structure for r in records).encode("ascii"), np.uint8)
+    return ShardText(bases.copy(), marks.copy(), node_ptr, edge_ptr, spec)
+
+
 def partition_records(records: Iterable[RNA], *, max_records: int,
                       max_nodes: int | None = None
                       ) -> Iterator[tuple[RNA, ...]]:
@@ -631,6 +698,7 @@ from .shard_io import (graph_metadata_path, load_graph_shard,  # noqa: E402
 __all__ = [
     "GRAPH_SHARD_FORMAT", "GRAPH_SHARD_FORMAT_VERSION", "NODE_ROLE_CONTEXT",
     "NODE_ROLE_CORE", "Graph", "GraphBuilder", "GraphCompatibilityError",
-    "GraphShard", "GraphSpec", "GraphValidationError", "graph_metadata_path",
-    "load_graph_shard", "pair_table", "partition_records", "save_graph_shard",
+    "GraphShard", "GraphSpec", "GraphValidationError", "ShardText",
+    "graph_metadata_path", "load_graph_shard", "pair_table", "partition_records",
+    "save_graph_shard", "shard_text",
 ]

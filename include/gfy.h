@@ -80,6 +80,34 @@ int gfy_encoder_create(const void* weight_pack_host, size_t bytes,
                        int model_dtype, int device, gfy_encoder** out);
 void gfy_encoder_destroy(gfy_encoder* encoder);
 
+/* ---- records -> graph arrays (MI355X-side extension of the path's caller) ---------
+ * GraphBuilder._build_full for every unsliced record of a micro-batch, concatenated as
+ * GraphShard.from_graphs does (src/ginfinity/graph.py:494-561 — node features 496-514,
+ * typed edges 516-546, pair table 737-747; concatenation 346-412).  Integer / one-hot
+ * work, bit-identical to the reference's arrays including the edge order.
+ *   bases, marks   uint8 [N]     the records' sequence / dot-bracket text, concatenated
+ *                                (A C G U and ( . ) only — RNA.__post_init__ guarantees it)
+ *   node_ptr       int64 [R+1]   record r owns nodes node_ptr[r]-node_ptr[0] ..
+ *   edge_ptr       int64 [R+1]   and edges edge_ptr[r]-edge_ptr[0] ..; the caller computes
+ *                                it: 2(L-1) + 2 pairs + (skip2 ? 2 max(L-2,0) : 0) per record
+ *   struct_states  1: one "paired" flag (struct_feature "A"); 3: one-hot ( . )  ("B")
+ *   positional     float32 [N][positional_columns] or NULL: the reference's host numpy
+ *                  float32 sin/cos columns, copied into the feature rows unchanged
+ *   node_features  float32 [N][4 + struct_states + positional_columns]   out
+ *   edge_index     int32 [2][E], edge_types uint8 [E]                     out
+ *   first_invalid  int32 [1] out: -1, or the first record whose text is not a balanced
+ *                  structure over the alphabet, disagrees with edge_ptr, or nests deeper
+ *                  than 2,048 levels (the reference caps records at 4,096 nt,
+ *                  _validation.py MAXIMUM_LENGTH_NT); its rows are then unspecified,
+ *                  nothing is written out of bounds.  No workspace.                 */
+int gfy_build_graphs(const uint8_t* bases, const uint8_t* marks,
+                     const int64_t* node_ptr, const int64_t* edge_ptr,
+                     int64_t n_records, int64_t n_nodes, int64_t n_edges,
+                     int struct_states, int positional_columns, int skip2,
+                     const float* positional, float* node_features,
+                     int32_t* edge_index, uint8_t* edge_types,
+                     int32_t* first_invalid, void* stream);
+
 /* ---- COO -> CSR ------------------------------------------------------------
  * Destination-major CSR of a shard's edges, edges of one destination kept in
  * their COO order (a stable counting sort; integer work, bit-exact, run-to-run

@@ -314,3 +314,31 @@ def test_cli_host_only_commands(tmp_path, capsys):
     assert main(["build-graphs", "--input", str(tmp_path / "missing.tsv"),
                  "--output", str(graphs)]) == 2
     assert "ginfinity:" in capsys.readouterr().err
+
+
+def test_shard_text_offsets_and_positional_columns_equal_the_builder(rouskin_records):
+    """What the host hands to the device builder (gfy_build_graphs): record offsets from
+    lengths and '(' counts, and the numpy float32 sin / cos columns — the same numbers the
+    host builder puts into a GraphShard, for whole shards and for record ranges."""
+    from ginfinity_amd.graph import shard_text
+    records = rouskin_records[:400] + [RNA("one", "A", "."), RNA("two", "AU", "()"),
+                                       RNA("three", "ACG", "...")]
+    for spec in (GraphSpec.bundled(),
+                 GraphSpec(struct_feature="B", positional=True, edge_dim=10, extra_edges=())):
+        want = GraphBuilder(spec).build_shard(records)
+        text = shard_text(records, spec)
+        np.testing.assert_array_equal(text.node_ptr, want.node_ptr)
+        np.testing.assert_array_equal(text.edge_ptr, want.edge_ptr)
+        assert text.bases.tobytes() == "".join(want.sequences).encode()
+        assert text.marks.tobytes() == "".join(want.structures).encode()
+        for start, stop in ((0, len(records)), (17, 230), (400, 403)):
+            piece = want if (start, stop) == (0, len(records)) else want.slice(start, stop)
+            columns = text.positional(start, stop)
+            assert columns.tobytes() == np.ascontiguousarray(
+                piece.node_features[:, -2:]).tobytes()
+    plain = GraphSpec(struct_feature="A", positional=False, edge_dim=10, extra_edges=("skip2",))
+    assert shard_text(records, plain).positional(0, 5) is None
+    with pytest.raises(GraphValidationError, match="duplicate"):
+        shard_text([records[0], records[0]], GraphSpec.bundled())
+    with pytest.raises(ValueError, match="unsliced"):
+        shard_text([RNA("w", "ACGUACGU", "((....))", start=2, end=5)], GraphSpec.bundled())
