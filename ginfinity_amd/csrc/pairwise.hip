@@ -7,11 +7,13 @@
 //   cosine  S_ij = a_i.b_j / (max(|a_i|,1e-12) max(|b_j|,1e-12))
 // oracle: oracle/gine_numpy.py pairwise_l2 / pairwise_cosine (float64).
 //
-// One kernel serves both outputs.  A workgroup (4 waves, 2x2) owns 128 a-rows,
-// whose MFMA fragments stay in registers, and sweeps its chunk of b-rows in
-// 128-row tiles that LDS-DMA (global_load_lds_dwordx4) lands in one of two LDS
-// buffers a tile ahead; every lane fetches the 16-byte chunk that belongs in its
+// One kernel serves both outputs.  A workgroup (8 waves, 4x2, one per CU) owns 256
+// a-rows, whose MFMA fragments stay in registers, and sweeps its chunk of b-rows in
+// 128-row tiles that LDS-DMA (global_load_lds_dwordx4) lands in a ring of four LDS
+// buffers three tiles ahead; every lane fetches the 16-byte chunk that belongs in its
 // slot of the XOR-swizzled layout, so no register ever holds b-rows in flight.
+// (Every workgroup streams all of B: 256 a-rows per workgroup instead of 128 halves
+// that traffic — 1M x 1M: 2 TB -> 1 TB through L2 — and is what the ring's LDS buys.)
 // The product is taken as (B-tile) x (A-block)^T so the a-row sits on the MFMA
 // lane: the running best of an a-row is lane-local state and a lane's four
 // consecutive accumulator registers are four consecutive b-rows.
@@ -27,9 +29,10 @@
 namespace gfy {
 namespace {
 
-constexpr int kBlockA = 128;  // a-rows per workgroup
+constexpr int kBlockA = 256;  // a-rows per workgroup
 constexpr int kTileB = 128;   // b-rows per LDS tile
-constexpr int kThreads = 256;
+constexpr int kThreads = 512;
+constexpr int kBuffers = 4;   // b-tile ring: tile i is consumed while i+1 .. i+3 are in flight
 
 __device__ __forceinline__ int off256(int row, int chunk) {
   return row * 256 + ((chunk ^ (row & 15)) << 4);
@@ -84,45 +87,72 @@ struct PairArgs {
   float* dense;         // [n][m]        (dense)
 };
 
-constexpr int kBufBytes = kTileB * 256 + 2 * kTileB * 4;   // b-tile + its (s, t)
+constexpr int kRowBytes = kTileB * 256;        // one b-tile of rows
+constexpr int kTermBytes = 2 * kTileB * 4;     // its (s, t)
+constexpr int kTermSlots = 8;                  // (s, t) live in a longer ring than the rows:
+                                               // the late waves reduce tile i-1 during tile i
 
 template <bool kDense>
-__global__ __launch_bounds__(kThreads, 2) void k_pairwise(const PairArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // two buffers
+__global__ __launch_bounds__(kThreads, 1) void k_pairwise(const PairArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // kBuffers buffers
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int r = lane & 31, hq = lane >> 5;
-  const int wa = wave & 1, wb = wave >> 1;  // wave owns a-rows [64wa,64wa+64), b-rows [64wb, 64wb+64) of each tile
+  // wave owns a-rows [128wa, 128wa+128) and b-rows [32wb, 32wb+32) of each tile: one b operand
+  // read from LDS feeds FOUR MFMAs (with 64 x 64 per wave it fed two, and the kernel was bound
+  // by ds_read_b128 traffic: 58 % of the MFMA peak with DMA, barrier and epilogue all removed)
+  const int wa = wave & 1, wb = wave >> 1;
   const int chunk = blockIdx.x / p.blocks_a;
   const int block_a = blockIdx.x - chunk * p.blocks_a;
   const int64_t a0 = (int64_t)block_a * kBlockA;
   const int64_t j_begin = (int64_t)chunk * p.chunk_rows;
   const int64_t j_end = j_begin + p.chunk_rows < p.m ? j_begin + p.chunk_rows : p.m;
 
-  // one b-tile -> buffer `buf`: 128 rows as 32 DMA instructions (8 per wave, 4 rows each),
+  // one b-tile -> buffer `buf`: 128 rows as 32 DMA instructions (4 per wave, 4 rows each),
   // (s, t) as one more by waves 0 and 1.  Rows past the end re-read the last row; their
   // t is +inf (k_row_terms pads s/t to whole tiles).
-  auto request = [&](int64_t j0, int buf) {
-    const uint32_t base = lds0 + (uint32_t)buf * kBufBytes;
-    const int sub = lane >> 4, slot = lane & 15;
+  // Per-lane byte offset of its 16-byte piece q inside a tile: row 16 wave + 4 q + sub, slot
+  // (lane & 15) ^ (row & 15)  =  (home ^ (q << 6)) + 1024 q  with ONE loop-invariant register
+  // (`home`); the tile's base travels in SGPRs.  (64-bit per-lane pointers, or the four
+  // offsets kept in registers, spilled — and a scratch reload is a vmcnt(0) wait that drains
+  // the DMA look-ahead.  The asm keeps hipcc from hoisting them out of the loop again.)
+  // `home` is rebuilt from threadIdx.x per request (six VALU operations): any loop-invariant
+  // register here is one that hipcc spills.
+  auto request = [&](int k) {   // tile k of this workgroup's sweep
+    const int64_t j0 = j_begin + (int64_t)k * kTileB;
+    const uint32_t base = lds0 + (uint32_t)(k & (kBuffers - 1)) * kRowBytes;
+    const f16* rows = p.b + j0 * 128;   // wave-uniform
+    uint32_t me = threadIdx.x;
+    asm volatile("" : "+v"(me));
+    const uint32_t sub = (me >> 4) & 3u, slot = me & 15u;
+    const uint32_t at_home = ((uint32_t)(16 * wave) + sub) * 256u + ((slot ^ sub) << 4);
+    if (j0 + kTileB <= p.m) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int g = wave * 8 + q;
-      const int row = 4 * g + sub;
-      int64_t j = j0 + row;
-      j = j < p.m ? j : p.m - 1;
-      dma16_at(p.b + j * 128 + (slot ^ (row & 15)) * 8, base + (uint32_t)g * 1024u);
+      for (int q = 0; q < 4; ++q)
+        dma16(rows, (at_home ^ (uint32_t)(q << 6)) + 1024u * q,
+              base + (uint32_t)(wave * 4 + q) * 1024u);
+    } else {   // ragged last tile: rows past the end re-read the last row (their t is +inf)
+      const int last = (int)(p.m - 1 - j0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t full = (at_home ^ (uint32_t)(q << 6)) + 1024u * q;
+        const int row = (int)(full >> 8);   // 16 wave + 4 q + sub
+        const int from = row < last ? row : last;
+        dma16(rows, (uint32_t)from * 256u + (full & 255u),
+              base + (uint32_t)(wave * 4 + q) * 1024u);
+      }
     }
-    if (wave < 2 && lane < 32)   // 128 floats = 32 lanes x 16 B
-      dma16_at((wave == 0 ? p.s : p.t) + j0 + lane * 4,
-               base + kTileB * 256 + (uint32_t)wave * (kTileB * 4));
+    if (wave < 2 && (me & 32u) == 0)   // 128 floats = 32 lanes x 16 B
+      dma16((wave == 0 ? p.s : p.t) + j0, (me & 31u) * 16u,
+            lds0 + kBuffers * kRowBytes + (uint32_t)(k & (kTermSlots - 1)) * kTermBytes
+                + (uint32_t)wave * (kTileB * 4));
   };
 
   // stage the a-block through LDS once (coalesced), then keep ALL its fragments in registers
   {
-    char* atile = smem + kBufBytes;   // second buffer, not yet in use
+    char* atile = smem + kRowBytes;   // buffers 1 and 2 (64 KB), not yet in use
     for (int i = t; i < kBlockA * 16; i += kThreads) {
       const int row = i >> 4, ch = i & 15;
       f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -130,159 +160,186 @@ __global__ __launch_bounds__(kThreads, 2) void k_pairwise(const PairArgs p) {
       *reinterpret_cast<f16x8*>(atile + off256(row, ch)) = v;
     }
   }
-  if (j_begin < j_end) request(j_begin, 0);
+  if (j_begin < j_end) request(0);
   __syncthreads();
-  f16x8 af[2][8];
+  f16x8 af[4][8];
 #pragma unroll
-  for (int at = 0; at < 2; ++at)
+  for (int at = 0; at < 4; ++at)
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
       af[at][ks] = *reinterpret_cast<const f16x8*>(
-          smem + kBufBytes + off256(64 * wa + 32 * at + r, 2 * ks + hq));
+          smem + kRowBytes + off256(128 * wa + 32 * at + r, 2 * ks + hq));
 
-  float best[2];
-  int bidx[2];
+  float best[4];
+  int bidx[4];
 #pragma unroll
-  for (int at = 0; at < 2; ++at) {
+  for (int at = 0; at < 4; ++at) {
     best[at] = __builtin_inff();
     bidx[at] = 0x7fffffff;
   }
 
-  int cur = 0;
-  for (int64_t j0 = j_begin; j0 < j_end; j0 += kTileB, cur ^= 1) {
-    // this wave's share of tile j0 has landed; the barrier publishes everybody's and tells
-    // us that the other buffer (tile j0 - 128, or the a-block) is no longer being read
-    dma_wait_all();
-    __syncthreads();
-    if (j0 + kTileB < j_end) request(j0 + kTileB, cur ^ 1);
-    const char* tile = smem + cur * kBufBytes;
-    const float* s_l = reinterpret_cast<const float*>(tile + kTileB * 256);
-    const float* t_l = s_l + kTileB;
+  // the a-block has left buffers 1 and 2: two more tiles go in flight
+  __syncthreads();
+  const int tiles = j_begin < j_end ? (int)((j_end - j_begin + kTileB - 1) / kTileB) : 0;
+  if (tiles > 1) request(1);
+  if (tiles > 2) request(2);
 
-    // does this tile contain an excluded (i, i + offset) pair of this block?
-    const int64_t ex_lo = a0 + p.exclude_offset, ex_hi = ex_lo + kBlockA;
-    const bool may_exclude = p.exclude_offset >= 0 && ex_lo < j0 + kTileB && ex_hi > j0;
-
-    // the wave's 64 x 64 block of this tile: four independent accumulator chains (a
-    // 32x32x16 MFMA that reads the previous one's result stalls the issue port; two chains
-    // per wave left 46 % of the wave cycles in that stall), b operands read one k-step ahead
-    f32x16 acc4[2][2];   // [bt][at]
+  // the wave's 32 x 128 block of tile k: four independent accumulator chains (a 32x32x16
+  // MFMA that reads the previous one's result stalls the issue port), the b operand read
+  // kAheadK k-steps ahead
+  f32x16 acc[4];   // [at]
+  auto multiply = [&](int k) {
+    const char* tile = smem + (k & (kBuffers - 1)) * kRowBytes;
 #pragma unroll
-    for (int bt = 0; bt < 2; ++bt)
+    for (int at = 0; at < 4; ++at)
 #pragma unroll
-      for (int at = 0; at < 2; ++at)
+      for (int q = 0; q < 16; ++q) acc[at][q] = 0.f;
+    constexpr int kAheadK = 2, kRing = kAheadK + 1;
+    f16x8 bf[kRing];   // [ks % kRing]
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc4[bt][at][q] = 0.f;
-    {
-      f16x8 bf[2][2];   // [parity of ks][bt]
+    for (int ks = 0; ks < kAheadK; ++ks)
+      bf[ks] = *reinterpret_cast<const f16x8*>(tile + off256(32 * wb + r, 2 * ks + hq));
 #pragma unroll
-      for (int bt = 0; bt < 2; ++bt)
-        bf[0][bt] = *reinterpret_cast<const f16x8*>(tile + off256(64 * wb + 32 * bt + r, hq));
+    for (int ks = 0; ks < 8; ++ks) {
+      if (ks + kAheadK < 8)
+        bf[(ks + kAheadK) % kRing] = *reinterpret_cast<const f16x8*>(
+            tile + off256(32 * wb + r, 2 * (ks + kAheadK) + hq));
+      // hipcc otherwise sinks every operand read down to its MFMAs (one register quad,
+      // read -> lgkmcnt(0) -> MFMAs: the LDS latency exposed eight times a tile)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        if (ks < 7) {
-#pragma unroll
-          for (int bt = 0; bt < 2; ++bt)
-            bf[(ks + 1) & 1][bt] = *reinterpret_cast<const f16x8*>(
-                tile + off256(64 * wb + 32 * bt + r, 2 * (ks + 1) + hq));
-        }
-#pragma unroll
-        for (int bt = 0; bt < 2; ++bt)
-#pragma unroll
-          for (int at = 0; at < 2; ++at)
-            acc4[bt][at] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ks & 1][bt], af[at][ks],
-                                                                  acc4[bt][at], 0, 0, 0);
-      }
+      for (int at = 0; at < 4; ++at)
+        acc[at] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ks % kRing], af[at][ks], acc[at],
+                                                         0, 0, 0);
     }
+  };
+
+  // what happens to the products of tile k (still in acc)
+  const int jw = 32 * wb + 4 * hq;   // first of this lane's b-rows inside a tile
+  auto reduce = [&](int k) {
+    const int64_t j0 = j_begin + (int64_t)k * kTileB;
+    const float* s_l = reinterpret_cast<const float*>(
+        smem + kBuffers * kRowBytes + (k & (kTermSlots - 1)) * kTermBytes);
+    const float* t_l = s_l + kTileB;
+    if constexpr (kDense) {
 #pragma unroll
-    for (int bt = 0; bt < 2; ++bt) {
-      f32x16(&accs)[2] = acc4[bt];
-      if constexpr (kDense) {
+      for (int g = 0; g < 4; ++g) {
+        const int jl = jw + 8 * g;  // 4 consecutive b-rows
+        const f32x4 sv = *reinterpret_cast<const f32x4*>(s_l + jl);
+        const f32x4 tv = *reinterpret_cast<const f32x4*>(t_l + jl);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int jl = 64 * wb + 32 * bt + 8 * g + 4 * hq;  // 4 consecutive b-rows
-          const f32x4 sv = *reinterpret_cast<const f32x4*>(s_l + jl);
-          const f32x4 tv = *reinterpret_cast<const f32x4*>(t_l + jl);
+        for (int at = 0; at < 4; ++at) {
+          const int64_t ai = a0 + 128 * wa + 32 * at + r;
+          const float aterm = ai < p.n ? p.a_term[ai] : 0.f;
 #pragma unroll
-          for (int at = 0; at < 2; ++at) {
-            const int64_t ai = a0 + 64 * wa + 32 * at + r;
-            const float aterm = ai < p.n ? p.a_term[ai] : 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const int64_t j = j0 + jl + i;
-              const float key = __builtin_fmaf(accs[at][4 * g + i], sv[i], tv[i]);
-              if (ai < p.n && j < p.m) {
-                float val;
-                if (p.metric == GFY_L2) {
-                  const float d2 = aterm + key;
-                  val = __builtin_sqrtf(d2 > 0.f ? d2 : 0.f);
-                } else {
-                  val = -key * aterm;
-                }
-                p.dense[ai * p.m + j] = val;
+          for (int i = 0; i < 4; ++i) {
+            const int64_t j = j0 + jl + i;
+            const float key = __builtin_fmaf(acc[at][4 * g + i], sv[i], tv[i]);
+            if (ai < p.n && j < p.m) {
+              float val;
+              if (p.metric == GFY_L2) {
+                const float d2 = aterm + key;
+                val = __builtin_sqrtf(d2 > 0.f ? d2 : 0.f);
+              } else {
+                val = -key * aterm;
               }
+              p.dense[ai * p.m + j] = val;
             }
           }
         }
-      } else {
-        __builtin_amdgcn_sched_barrier(0);   // keep the next b-tile's operand reads behind us
-        // The contraction is only 128 deep, so an epilogue of fma + compare + two selects
-        // per element costs more vector cycles than the MFMAs that produced it.  Instead:
-        // 16 keys per a-row with packed fmas, their minimum with v_min3 (~1 instruction per
-        // element in all), and the position of the minimum is recovered only while some
-        // lane of the wave still improves its running best — soon rare.
-#pragma unroll
-        for (int at = 0; at < 2; ++at) {
-          const int64_t ai = a0 + 64 * wa + 32 * at + r;
-          f32x4 key[4];   // one a-row's 16 keys at a time (registers); s/t are re-read per a-tile
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int jl = 64 * wb + 32 * bt + 8 * g + 4 * hq;  // 4 consecutive b-rows
-            const f32x4 sv = *reinterpret_cast<const f32x4*>(s_l + jl);
-            const f32x4 tv = *reinterpret_cast<const f32x4*>(t_l + jl);
-            f32x4 a4;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a4[i] = accs[at][4 * g + i];
-            key[g] = __builtin_elementwise_fma(a4, sv, tv);
-          }
-          if (may_exclude) {   // block-uniform, at most two tiles per block
-            // the one excluded b-row of this a-row, as a position among the lane's 16 keys
-            const int64_t off = ai + p.exclude_offset - (j0 + 64 * wb + 32 * bt + 4 * hq);
-            const int d = off >= 0 && off < 32 ? (int)off : 4;   // 4: not a position of this lane
-            const int slot = (d & 4) ? -1 : (d >> 3) * 4 + (d & 3);
-#pragma unroll
-            for (int q = 0; q < 16; ++q)
-              key[q >> 2][q & 3] = q == slot ? __builtin_inff() : key[q >> 2][q & 3];
-          }
-          float low = __builtin_fminf(key[0][0], key[0][1]);
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int i = (g == 0 ? 2 : 0); i < 4; i += 2)
-              low = __builtin_fminf(__builtin_fminf(low, key[g][i]), key[g][i + 1]);   // v_min3_f32
-          const bool better = low < best[at];   // strict: an earlier tile keeps a tie
-          if (__ballot(better)) {               // wave-uniform skip once the sweep has settled
-            int first = 15;                     // lowest position holding the minimum
-#pragma unroll
-            for (int q = 14; q >= 0; --q) first = key[q >> 2][q & 3] == low ? q : first;
-            const int j = (int)(j0 + 64 * wb + 32 * bt + 8 * (first >> 2) + 4 * hq + (first & 3));
-            best[at] = better ? low : best[at];
-            bidx[at] = better ? j : bidx[at];
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
       }
+    } else {
+      // does this tile contain an excluded (i, i + offset) pair of this block?
+      const int64_t ex_lo = a0 + p.exclude_offset, ex_hi = ex_lo + kBlockA;
+      const bool may_exclude = p.exclude_offset >= 0 && ex_lo < j0 + kTileB && ex_hi > j0;
+      __builtin_amdgcn_sched_barrier(0);
+      // The contraction is only 128 deep, so an epilogue of fma + compare + two selects
+      // per element costs more vector cycles than the MFMAs that produced it.  Instead:
+      // 16 keys per a-row with packed fmas, their minimum with v_min3 (~1 instruction per
+      // element in all), and the position of the minimum is recovered only while some
+      // lane of the wave still improves its running best — soon rare.
+#pragma unroll
+      for (int at = 0; at < 4; ++at) {
+        f32x4 key[4];   // one a-row's 16 keys at a time (registers); s/t are re-read per a-tile
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int jl = jw + 8 * g;  // 4 consecutive b-rows
+          const f32x4 sv = *reinterpret_cast<const f32x4*>(s_l + jl);
+          const f32x4 tv = *reinterpret_cast<const f32x4*>(t_l + jl);
+          f32x4 a4;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) a4[i] = acc[at][4 * g + i];
+          key[g] = __builtin_elementwise_fma(a4, sv, tv);
+        }
+        if (may_exclude) {   // block-uniform, at most three tiles per block
+          // the one excluded b-row of this a-row, as a position among the lane's 16 keys
+          const int64_t off = (a0 + p.exclude_offset - j0) + (128 * wa + 32 * at + r - jw);
+          const int d = off >= 0 && off < 32 ? (int)off : 4;   // 4: not a position of this lane
+          const int slot = (d & 4) ? -1 : (d >> 3) * 4 + (d & 3);
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            key[q >> 2][q & 3] = q == slot ? __builtin_inff() : key[q >> 2][q & 3];
+        }
+        float low = __builtin_fminf(key[0][0], key[0][1]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int i = (g == 0 ? 2 : 0); i < 4; i += 2)
+            low = __builtin_fminf(__builtin_fminf(low, key[g][i]), key[g][i + 1]);   // v_min3_f32
+        const bool better = low < best[at];   // strict: an earlier tile keeps a tie
+        if (__ballot(better)) {               // wave-uniform skip once the sweep has settled
+          int first = 15;                     // lowest position holding the minimum
+#pragma unroll
+          for (int q = 14; q >= 0; --q) first = key[q >> 2][q & 3] == low ? q : first;
+          const int j = (int)(j0 + jw + 8 * (first >> 2) + (first & 3));
+          best[at] = better ? low : best[at];
+          bidx[at] = better ? j : bidx[at];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
+  };
+
+  // Barrier k: wait for this wave's share of tile k only — the DMA instructions of the (up
+  // to two) younger requests stay in flight, 4 per request, 5 on the waves that fetch
+  // (s, t) — then the barrier, which publishes everybody's share and says that the rows of
+  // tile k - 1 are no longer being read, so tile k + 3 can be requested into their buffer.
+  auto sync = [&](int k) {
+    const int younger = tiles - 1 - k < 2 ? tiles - 1 - k : 2;
+    if (younger == 2) {
+      if (wave < 2) __builtin_amdgcn_s_waitcnt(0x0F7A); else __builtin_amdgcn_s_waitcnt(0x0F78);
+    } else if (younger == 1) {
+      if (wave < 2) __builtin_amdgcn_s_waitcnt(0x0F75); else __builtin_amdgcn_s_waitcnt(0x0F74);
+    } else {
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+    }
+    asm volatile("" ::: "memory");
+    __syncthreads();
+    if (k + 3 < tiles) request(k + 3);
+  };
+
+  // The two waves that share a SIMD (w and w + 4) run half a tile out of phase: between
+  // barriers k and k + 1 the early one multiplies tile k and reduces it, the late one
+  // reduces tile k - 1 and multiplies tile k — one wave's MFMAs run under the other's
+  // vector epilogue instead of all eight leaving the matrix pipe idle together.  Same
+  // instruction stream for both (multiply, reduce), only the barrier sits elsewhere.
+  const bool late = !kDense && wave >= 4;
+  if (late && tiles > 0) sync(0);
+  for (int ti = 0; ti < tiles; ++ti) {
+    if (!late) sync(ti);
+    multiply(ti);
+    if (late && ti + 1 < tiles) sync(ti + 1);
+    reduce(ti);
   }
   __syncthreads();   // the result merge below reuses the first buffer
 
   if constexpr (!kDense) {
     // merge the two lane halves (different b-rows, same a-row), then the two
     // waves that share this a-row range (wb = 0/1) through LDS
-    float* m_val = reinterpret_cast<float*>(smem);          // [2 wb][128]
-    int* m_idx = reinterpret_cast<int*>(smem + 2 * kBlockA * 4);
+    float* m_val = reinterpret_cast<float*>(smem);          // [4 wb][kBlockA]
+    int* m_idx = reinterpret_cast<int*>(smem + 4 * kBlockA * 4);
 #pragma unroll
-    for (int at = 0; at < 2; ++at) {
+    for (int at = 0; at < 4; ++at) {
       const float ov = __shfl_xor(best[at], 32, 64);
       const int oi = __shfl_xor(bidx[at], 32, 64);
       if (ov < best[at] || (ov == best[at] && oi < bidx[at])) {
@@ -290,17 +347,22 @@ __global__ __launch_bounds__(kThreads, 2) void k_pairwise(const PairArgs p) {
         bidx[at] = oi;
       }
       if (hq == 0) {
-        m_val[wb * kBlockA + 64 * wa + 32 * at + r] = best[at];
-        m_idx[wb * kBlockA + 64 * wa + 32 * at + r] = bidx[at];
+        m_val[wb * kBlockA + 128 * wa + 32 * at + r] = best[at];
+        m_idx[wb * kBlockA + 128 * wa + 32 * at + r] = bidx[at];
       }
     }
     __syncthreads();
     if (t < kBlockA && a0 + t < p.n) {
-      float v0 = m_val[t], v1 = m_val[kBlockA + t];
-      int i0 = m_idx[t], i1 = m_idx[kBlockA + t];
-      if (v1 < v0 || (v1 == v0 && i1 < i0)) {
-        v0 = v1;
-        i0 = i1;
+      float v0 = m_val[t];
+      int i0 = m_idx[t];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const float v1 = m_val[w * kBlockA + t];
+        const int i1 = m_idx[w * kBlockA + t];
+        if (v1 < v0 || (v1 == v0 && i1 < i0)) {
+          v0 = v1;
+          i0 = i1;
+        }
       }
       p.part_val[(int64_t)chunk * p.n + a0 + t] = v0;
       p.part_idx[(int64_t)chunk * p.n + a0 + t] = i0;
@@ -371,7 +433,7 @@ PairWorkspace carve(void* base, int64_t n, int64_t m) {
   return w;
 }
 
-constexpr int kPairLds = 2 * kBufBytes;   // two b-tile buffers (the second stages the a-block first)
+constexpr int kPairLds = kBuffers * kRowBytes + kTermSlots * kTermBytes;   // row ring (buffers 1, 2 stage the a-block first) + (s, t) ring
 
 }  // namespace
 

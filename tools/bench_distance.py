@@ -41,7 +41,12 @@ def main() -> None:
         "rows": args.rows, "distance": args.metric, "seconds": best,
         "pairs_per_s": args.rows * args.rows / best,
         "roofline": {"bound": "mfma", "achieved": flops / best / 1e12, "peak": 2500.0,
-                     "unit": "TFLOP/s", "frac": flops / best / 1e12 / 2500.0},
+                     "unit": "TFLOP/s", "frac": flops / best / 1e12 / 2500.0,
+                     # what a pure v_mfma_f32_32x32x16_f16 loop (no memory) sustains on this
+                     # part with random-mantissa operands: tools/mfma_peak.hip,
+                     # profiles/r01c_mfma_peak.txt (2,433 with small-integer operands)
+                     "sustained_mfma_measured": 1780.0,
+                     "frac_of_sustained": flops / best / 1e12 / 1780.0},
         "all_seconds": times,
         "sample": {"value0": float(values[0]), "index0": int(indices[0])}}))
 
