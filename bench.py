@@ -62,6 +62,9 @@ def parse() -> argparse.Namespace:
     parser.add_argument("--warmup", type=int, default=100)
     parser.add_argument("--streams", type=int, default=4,
                         help="independent shards in flight per GPU (HIP streams)")
+    parser.add_argument("--layer-workgroups", type=int, default=0,
+                        help="cap of the layer kernel's grid (0 = 256 with three or more "
+                             "streams, else the library default 512)")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--cpu-seconds", type=float, default=12.0)
     return parser.parse_args()
@@ -122,7 +125,7 @@ def main() -> None:
     lanes = max(1, args.streams)
     encoders = [Ginfinity.load(f"cuda:{local_rank}") for _ in range(lanes)]
     engines = [e._engine for e in encoders]
-    layer_workgroups = 256 if lanes >= 3 else 512
+    layer_workgroups = args.layer_workgroups or (256 if lanes >= 3 else 512)
     for e in engines:   # several layer launches in flight: let two of them share every CU
         e.set_layer_workgroups(0 if layer_workgroups == 512 else layer_workgroups)
     streams = [torch.cuda.Stream(device=device) for _ in range(lanes)]
