@@ -36,4 +36,10 @@ timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LD
 # 5. C++ driver (no Python in the loop) and in-kernel phase stamps (diagnostic build)
 timeout -k 10 100 $R/tools/gfy_bench 60000 200 > $OUT/gfy_bench.txt 2>&1 || exit 1
 timeout -k 10 100 $R/tools/gfy_bench_stamps 60000 50 > $OUT/gfy_bench_stamps.txt 2>&1 || exit 1
+
+# 6. the other measured paths: all-pairs distance (config 4), API level incl. PCIe (config 2),
+#    and what a pure MFMA loop sustains on this part
+timeout -k 10 300 python3 $R/tools/bench_distance.py > $OUT/distance_bench.json 2> $OUT/distance.err || exit 1
+timeout -k 10 300 python3 $R/tools/bench_api.py > $OUT/api_bench.json 2> $OUT/api.err || exit 1
+timeout -k 10 100 $R/tools/mfma_peak > $OUT/mfma_peak.txt 2>&1 || exit 1
 echo done
