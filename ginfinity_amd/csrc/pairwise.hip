@@ -89,8 +89,7 @@ struct PairArgs {
 
 constexpr int kRowBytes = kTileB * 256;        // one b-tile of rows
 constexpr int kTermBytes = 2 * kTileB * 4;     // its (s, t)
-constexpr int kTermSlots = 8;                  // (s, t) live in a longer ring than the rows:
-                                               // the late waves reduce tile i-1 during tile i
+constexpr int kTermSlots = 4;                  // (s, t) ring, like the rows
 
 template <bool kDense>
 __global__ __launch_bounds__(kThreads, 1) void k_pairwise(const PairArgs p) {
@@ -318,17 +317,11 @@ __global__ __launch_bounds__(kThreads, 1) void k_pairwise(const PairArgs p) {
     if (k + 3 < tiles) request(k + 3);
   };
 
-  // The two waves that share a SIMD (w and w + 4) run half a tile out of phase: between
-  // barriers k and k + 1 the early one multiplies tile k and reduces it, the late one
-  // reduces tile k - 1 and multiplies tile k — one wave's MFMAs run under the other's
-  // vector epilogue instead of all eight leaving the matrix pipe idle together.  Same
-  // instruction stream for both (multiply, reduce), only the barrier sits elsewhere.
-  const bool late = !kDense && wave >= 4;
-  if (late && tiles > 0) sync(0);
+  // (Running the two waves of a SIMD half a tile out of phase — one multiplies while the other
+  // reduces — was measured: no change, see profiles/README.md.)
   for (int ti = 0; ti < tiles; ++ti) {
-    if (!late) sync(ti);
+    sync(ti);
     multiply(ti);
-    if (late && ti + 1 < tiles) sync(ti + 1);
     reduce(ti);
   }
   __syncthreads();   // the result merge below reuses the first buffer
