@@ -1,0 +1,52 @@
+"""bench.py prints ONE JSON line with the keys the driver reads (the contract in the task
+statement), plus the `roofline` and `cpu_baseline` objects.  Run as a child process, the way
+the driver runs it."""
+from __future__ import annotations
+
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _run(*flags: str) -> dict:
+    env = dict(os.environ, GFY_BENCH_SETTLE_S="0.05")
+    done = subprocess.run([sys.executable, str(ROOT / "bench.py"), *flags], cwd=ROOT, env=env,
+                          capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0, done.stderr[-2000:]
+    lines = [line for line in done.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1, done.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract():
+    line = _run("--steps", "40", "--warmup", "8", "--cpu-seconds", "1")
+    assert line["metric"] == "encoded nodes/sec on 60k-node/300k-edge shards"
+    assert line["unit"] == "nodes/s" and line["higher_is_better"] is True
+    assert (line["n_gpus"], line["steps"], line["warmup"]) == (1, 40, 8)
+    assert line["scaling"] == "weak" and line["vs_baseline"] is None
+    assert line["dtype"] == "f16" and line["data"] == "synthetic"
+    assert "workload" in line["config"] and "model" not in line["config"]
+    assert line["value"] > 1e8                      # an MI355X does hundreds of M nodes/s
+    assert abs(line["value"] - 60000 / (line["ms_per_step"] * 1e-3)) < 1e-3 * line["value"]
+    roof = line["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert 0.02 < roof["frac"] < 1.0
+    assert roof["traffic"] is None or roof["traffic"] >= roof["algorithmic_bytes_per_launch"]
+    cpu = line["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["unit"] == "nodes/s"
+    assert cpu["cores"] >= 1 and 0 < cpu["value"] < line["value"] and cpu["sample"]
+
+
+def test_bench_line_one_stream_without_cpu_baseline():
+    line = _run("--steps", "20", "--warmup", "4", "--streams", "1", "--no-cpu-baseline")
+    assert line["cpu_baseline"] is None and line["steps"] == 20
+    assert line["config"]["layer_workgroups"] == 512
