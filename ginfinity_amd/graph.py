@@ -648,21 +648,23 @@ def shard_text(records: Sequence[RNA], spec: GraphSpec) -> ShardText:
         raise GraphValidationError("a graph shard cannot be empty")
     if len({record.identifier for record in records}) != count:
         raise GraphValidationError("duplicate identifiers in graph shard")
-    lengths = np.fromiter((r.length for r in records), dtype=np.int64, count=count)
-    pairs = np.fromiter((r.structure.count("(") for r in records), dtype=np.int64,
-                        count=count)
+    sequences = [record.sequence for record in records]
+    lengths = np.fromiter(map(len, sequences), dtype=np.int64, count=count)
     node_ptr = np.zeros(count + 1, dtype=np.int64)
     np.cumsum(lengths, out=node_ptr[1:])
     if int(node_ptr[-1]) > _INT32_MAX:
         raise GraphValidationError(
             "graph shard exceeds the int32 node-index capacity; split it")
+    bases = np.frombuffer("".join(sequences).encode("ascii"), np.uint8)
+    marks = np.frombuffer("".join(record.structure for record in records).encode("ascii"),
+                          np.uint8)
+    # '(' per record, counted on the concatenated text (records are never empty)
+    pairs = np.add.reduceat((marks == _OPEN).astype(np.int64), node_ptr[:-1])
     per_record = 2 * np.maximum(lengths - 1, 0) + 2 * pairs
     if spec.has_skip2:
         per_record += 2 * np.maximum(lengths - 2, 0)
     edge_ptr = np.zeros(count + 1, dtype=np.int64)
     np.cumsum(per_record, out=edge_ptr[1:])
-    bases = np.frombuffer("".join(r.sequence for r in records).encode("ascii"), np.uint8)
-    marks = np.frombuffer("".join(r.structure for r in records).encode("ascii"), np.uint8)
     return ShardText(bases.copy(), marks.copy(), node_ptr, edge_ptr, spec)
 
 
