@@ -559,3 +559,32 @@ def test_layer_workgroup_cap_does_not_change_results(gpu_encoder):
             np.testing.assert_array_equal(engine.encode(x, csr).cpu().numpy(), default)
     finally:
         engine.set_layer_workgroups(0)
+
+
+def test_build_csr_and_encode_are_graph_capturable(gpu_encoder):
+    """include/gfy.h: the launching entry points only ENQUEUE (no allocation, no hidden
+    synchronisation), so one step can be captured into a HIP graph and replayed."""
+    import torch
+    from ginfinity_amd import synthetic
+    engine = gpu_encoder._engine
+    shard = synthetic.roofline_shard(3)
+    device = engine.device
+    x = torch.from_numpy(shard.node_features).to(device)
+    ei = torch.from_numpy(shard.edge_index).to(device)
+    et = torch.from_numpy(shard.edge_types).to(device)
+    out = torch.empty((shard.node_count, 128), dtype=torch.float16, device=device)
+    step = engine.prepare_step(x, ei, et, out)
+    stream = torch.cuda.Stream(device=device)
+    with torch.cuda.device(device):
+        step(stream.cuda_stream)
+        stream.synchronize()
+        want = out.clone()
+        out.zero_()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            step(stream.cuda_stream)
+        torch.cuda.synchronize()
+        assert not bool(out.any())              # capture enqueued nothing for real
+        graph.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(out, want)
