@@ -17,6 +17,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
+from .npz import write_npz
 from .api import Ginfinity, default_alignment_parameters
 from .graph import GraphBuilder
 from .shard_io import graph_metadata_path, load_graph_shard, save_graph_shard
@@ -56,8 +57,10 @@ def _load_encoder(args: argparse.Namespace) -> Ginfinity:
 
 
 def _write_npz(path: Path, names, arrays) -> None:
+    """The reference's ``np.savez_compressed`` archive (cli.py:85-88,158-163), members
+    deflated on all cores (ginfinity_amd/npz.py)."""
     path.parent.mkdir(parents=True, exist_ok=True)
-    np.savez_compressed(path, **dict(zip(names, arrays)))
+    write_npz(path, names, arrays)
 
 
 def _provenance(encoder: Ginfinity) -> dict:

@@ -171,3 +171,36 @@ def test_encode_many_on_device_built_graphs_equals_encode_graphs(gpu_encoder, dt
     differing = [i for i, (a, b) in enumerate(zip(small, want[:50]))
                  if a.dtype != b.dtype or a.tobytes() != b.tobytes()]
     assert not differing, differing
+
+
+def test_cli_embed_and_embed_graphs_write_the_reference_archives(tmp_path, capsys,
+                                                                 gpu_encoder, rouskin_records):
+    """`embed` (text in, device-built graphs) and `build-graphs` + `embed-graphs` produce the
+    same .npz — member per record, as np.savez_compressed wrote them in the reference
+    (cli.py:85-88,158-163) — plus the manifests."""
+    import json
+    from ginfinity_amd.cli import main
+    records = rouskin_records[:120]
+    table = tmp_path / "rna.tsv"
+    table.write_text("transcript_id\tsequence\tsecondary_structure\n" + "".join(
+        f"{r.identifier}\t{r.sequence}\t{r.structure}\n" for r in records))
+    direct = tmp_path / "direct.npz"
+    assert main(["embed", "--input", str(table), "--output", str(direct)]) == 0
+    printed = json.loads(capsys.readouterr().out)
+    assert printed["records"] == 120
+    manifest = json.loads((tmp_path / "direct.manifest.json").read_text())
+    assert manifest["status"] == "complete" and len(manifest["records"]) == 120
+    assert manifest["output_sha256"] and manifest["records"][3]["shape"][1] == 128
+
+    graphs = tmp_path / "g.safetensors"
+    assert main(["build-graphs", "--input", str(table), "--output", str(graphs)]) == 0
+    capsys.readouterr()
+    staged = tmp_path / "staged.npz"
+    assert main(["embed-graphs", "--input", str(graphs), "--output", str(staged),
+                 "--embedding-dtype", "float16"]) == 0
+    want = gpu_encoder.encode_many(records)
+    with np.load(direct) as a, np.load(staged) as b:
+        assert list(a.keys()) == [r.identifier for r in records] == list(b.keys())
+        for record, expected in zip(records, want):
+            assert a[record.identifier].tobytes() == expected.tobytes()
+            assert b[record.identifier].tobytes() == expected.tobytes()

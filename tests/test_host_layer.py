@@ -342,3 +342,40 @@ def test_shard_text_offsets_and_positional_columns_equal_the_builder(rouskin_rec
         shard_text([records[0], records[0]], GraphSpec.bundled())
     with pytest.raises(ValueError, match="unsliced"):
         shard_text([RNA("w", "ACGUACGU", "((....))", start=2, end=5)], GraphSpec.bundled())
+
+
+def test_parallel_npz_writer_is_read_back_like_savez_compressed(tmp_path):
+    """ginfinity_amd.npz.write_npz: the reference CLI's np.savez_compressed archive
+    (cli.py:85-88), members deflated on all cores — np.load and zipfile read it back."""
+    import zipfile
+    from ginfinity_amd.npz import write_npz
+    rng = np.random.default_rng(4)
+    names = [f"rec/{i}|x y" if i % 7 == 0 else f"r{i}" for i in range(300)]
+    arrays = [rng.standard_normal((int(rng.integers(1, 90)), 128)).astype(
+        (np.float16, np.float32, np.float64)[i % 3]) for i in range(300)]
+    arrays[5] = np.zeros((0, 128), np.float16)
+    written = write_npz(tmp_path / "emb", names, arrays, threads=3)
+    assert written.name == "emb.npz"
+    with zipfile.ZipFile(written) as archive:
+        assert archive.testzip() is None
+        assert archive.namelist() == [n + ".npy" for n in names]
+        assert all(info.compress_type == zipfile.ZIP_DEFLATED for info in archive.infolist())
+    with np.load(written) as back:
+        assert list(back.keys()) == names
+        for name, array in zip(names, arrays):
+            got = back[name]
+            assert got.dtype == array.dtype and got.shape == array.shape
+            assert got.tobytes() == array.tobytes()
+    # same payload as numpy's own writer
+    plain = [n for n in names if "/" not in n]
+    np.savez_compressed(tmp_path / "ref.npz", **{n: arrays[names.index(n)] for n in plain})
+    with np.load(tmp_path / "ref.npz") as ref, np.load(written) as back:
+        for n in plain:
+            assert ref[n].tobytes() == back[n].tobytes()
+    with pytest.raises(ValueError, match="duplicate"):
+        write_npz(tmp_path / "d.npz", ["a", "a"], arrays[:2])
+    # more than 65,535 members: the ZIP64 end-of-directory records
+    many = [np.float32([i]) for i in range(66000)]
+    big = write_npz(tmp_path / "many.npz", (f"m{i}" for i in range(66000)), many)
+    with np.load(big) as back:
+        assert len(back.files) == 66000 and float(back["m65999"][0]) == 65999.0
