@@ -113,3 +113,43 @@ def test_cross_shard_nearest_world_size_one(gpu_encoder):
     ref_values, ref_indices = distance.nearest(block, metric="cosine", exclude_self=True)
     np.testing.assert_array_equal(indices.cpu().numpy(), ref_indices.cpu().numpy())
     np.testing.assert_array_equal(values.cpu().numpy(), ref_values.cpu().numpy())
+
+
+@pytest.mark.parametrize("n,m", [(255, 129), (256, 128), (257, 385), (513, 640), (1, 513),
+                                 (770, 1)])
+def test_nearest_at_workgroup_and_tile_seams(n, m):
+    """k_pairwise owns 256 a-rows per workgroup and sweeps b in 128-row tiles through a ring
+    of four buffers: sizes one below / at / one above those seams, with and without an
+    excluded (i, i + k) pair that straddles them."""
+    from oracle import gine_numpy as G
+    from ginfinity_amd import distance
+    a, b = _rows(40 + n, n, unit=False), _rows(41 + m, m, unit=False)
+    full = G.pairwise_l2(a, b)
+    for offset in (None, 0, 127):
+        values, indices = distance.nearest(a, b, metric="l2", exclude_offset=offset)
+        values, indices = values.cpu().numpy().astype(np.float64), indices.cpu().numpy()
+        masked = full.copy()
+        if offset is not None:
+            rows = np.arange(n)
+            keep = rows + offset < m
+            masked[rows[keep], rows[keep] + offset] = np.inf
+        best = masked.min(axis=1)
+        reachable = np.isfinite(best)          # a single b-row that is excluded: nothing left
+        assert np.all(indices[~reachable] == -1)
+        picked = masked[np.arange(n)[reachable], indices[reachable]]
+        np.testing.assert_allclose(picked, best[reachable], rtol=0, atol=3e-3 * best.max())
+        np.testing.assert_allclose(values[reachable], picked, rtol=2e-3, atol=2e-3)
+
+
+def test_nearest_duplicates_across_tiles_and_sweep_chunks():
+    """Ties go to the lowest index also when the equal rows sit in different b-tiles, in
+    different ring buffers and — few a-rows, many b-rows — in different sweep chunks whose
+    partial results are merged by k_nearest_finish."""
+    from ginfinity_amd import distance
+    base = _rows(11, 90)
+    filler = _rows(12, 4000) * np.float16(0.5)           # never closer than an exact copy
+    b = np.concatenate([filler[:700], base, filler[700:2900], base, filler[2900:], base])
+    _, idx = distance.nearest(base, b, metric="l2")
+    np.testing.assert_array_equal(idx.cpu().numpy(), 700 + np.arange(90))
+    _, idx = distance.nearest(base, b, metric="cosine")
+    np.testing.assert_array_equal(idx.cpu().numpy(), 700 + np.arange(90))
