@@ -119,6 +119,55 @@ class _Downloader:
         return finish(host)
 
 
+class _Uploader:
+    """Several small host arrays → device tensors with ONE copy: they are packed into a
+    pinned staging buffer (ring of three, each guarded by the event of its last copy) and go
+    up as a single asynchronous H2D; the device tensors are views of one allocation.  Five
+    pageable ``tensor.to(device)`` per micro-batch were 0.4 ms of the launching thread."""
+
+    _TORCH = {np.dtype(np.uint8): torch.uint8, np.dtype(np.int64): torch.int64,
+              np.dtype(np.int32): torch.int32, np.dtype(np.float32): torch.float32}
+
+    def __init__(self, device: torch.device, slots: int = 3) -> None:
+        self._device = device
+        self._staging: list[torch.Tensor | None] = [None] * slots
+        self._copied: list["torch.cuda.Event | None"] = [None] * slots
+        self._next = 0
+
+    def __call__(self, arrays: Sequence[np.ndarray | None]) -> list[torch.Tensor | None]:
+        offsets, total = [], 0
+        for array in arrays:
+            offsets.append(total)
+            if array is not None:
+                total += -(-array.nbytes // 256) * 256
+        slot = self._next
+        self._next = (slot + 1) % len(self._staging)
+        if self._copied[slot] is not None:
+            self._copied[slot].synchronize()          # the slot's last copy has left it
+        staging = self._staging[slot]
+        if staging is None or staging.numel() < total:
+            staging = self._staging[slot] = torch.empty(
+                max(total, 1 << 20), dtype=torch.uint8, pin_memory=True)
+        host = staging.numpy()
+        for array, offset in zip(arrays, offsets):
+            if array is not None and array.nbytes:
+                host[offset:offset + array.nbytes] = np.ascontiguousarray(array).reshape(
+                    -1).view(np.uint8)
+        on_device = torch.empty(max(total, 1), dtype=torch.uint8, device=self._device)
+        on_device[:total].copy_(staging[:total], non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(self._device))
+        self._copied[slot] = done
+        views: list[torch.Tensor | None] = []
+        for array, offset in zip(arrays, offsets):
+            if array is None:
+                views.append(None)
+                continue
+            flat = on_device[offset:offset + array.nbytes].view(self._TORCH[array.dtype])
+            views.append(flat.view(array.shape))
+        return views
+
+
 class Ginfinity:
     """Loaded GINFINITY encoder, resident on one MI355X, ready for repeated
     inference."""
@@ -128,6 +177,7 @@ class Ginfinity:
         self._engine = engine
         self._copier: _Downloader | None = None
         self._preparer: ThreadPoolExecutor | None = None
+        self._uploader: _Uploader | None = None
         self._metadata = checkpoint.metadata
         self._config = checkpoint.config
         self._graph_spec = checkpoint.graph_spec
@@ -218,6 +268,8 @@ class Ginfinity:
         spec = self._graph_spec
         if self._copier is None:
             self._copier = _Downloader(device)
+        if self._uploader is None:
+            self._uploader = _Uploader(device)
         pending, verdicts = [], []
         bounds = microbatch_bounds(lengths, edge_counts, max_batch_nodes, max_batch_edges)
         # the positional columns (numpy sin / cos, GIL released) of later micro-batches are
@@ -230,11 +282,11 @@ class Ginfinity:
             n0, n1 = int(text.node_ptr[start]), int(text.node_ptr[stop])
             e0, e1 = int(text.edge_ptr[start]), int(text.edge_ptr[stop])
             columns = columns_job.result()
-            upload = lambda array: torch.from_numpy(array).to(device)   # noqa: E731
+            bases, marks, node_ptr, edge_ptr, positional = self._uploader(
+                (text.bases[n0:n1], text.marks[n0:n1], text.node_ptr[start:stop + 1],
+                 text.edge_ptr[start:stop + 1], columns))
             features, edge_index, edge_types, first_invalid = engine.build_graphs(
-                upload(text.bases[n0:n1]), upload(text.marks[n0:n1]),
-                upload(text.node_ptr[start:stop + 1]), upload(text.edge_ptr[start:stop + 1]),
-                None if columns is None else upload(columns), n1 - n0, e1 - e0,
+                bases, marks, node_ptr, edge_ptr, positional, n1 - n0, e1 - e0,
                 struct_states=1 if spec.struct_feature == "A" else 3,
                 skip2=spec.has_skip2)
             csr = engine.build_csr(edge_index, edge_types, n1 - n0)
@@ -302,6 +354,8 @@ class Ginfinity:
         torch_dtype, _code, exact = device_output_dtype(embedding_dtype)
         if self._copier is None:
             self._copier = _Downloader(self._engine.device)
+        if self._uploader is None:
+            self._uploader = _Uploader(self._engine.device)
         pending = []
         core_counts = shard.core_counts
         for start, stop in bounds:
@@ -310,10 +364,19 @@ class Ginfinity:
             # a GraphShard per micro-batch: that was 11 of this thread's 15 ms
             n0, n1 = int(shard.node_ptr[start]), int(shard.node_ptr[stop])
             e0, e1 = int(shard.edge_ptr[start]), int(shard.edge_ptr[stop])
-            block = self._engine.encode_arrays(
-                shard.node_features[n0:n1], shard.edge_index[:, e0:e1] - np.int32(n0),
-                shard.edge_types[e0:e1], shard.node_roles[n0:n1],
-                out_dtype=torch_dtype, normalise=True)
+            roles = shard.node_roles[n0:n1]
+            rows, kept = None, n1 - n0
+            if roles.any():                      # context nodes: dropped at the head's store
+                core = roles == 0
+                kept = int(np.count_nonzero(core))
+                rows = np.cumsum(core, dtype=np.int32) - np.int32(1)
+                rows[~core] = -1
+            features, edge_index, edge_types, out_rows = self._uploader(
+                (shard.node_features[n0:n1], shard.edge_index[:, e0:e1] - np.int32(n0),
+                 shard.edge_types[e0:e1], rows))
+            csr = self._engine.build_csr(edge_index, edge_types, n1 - n0)
+            block = self._engine.encode(features, csr, out_rows=out_rows, n_out=kept,
+                                        out_dtype=torch_dtype, normalise=True)
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(block.device))
             pending.append(self._copier.submit(
