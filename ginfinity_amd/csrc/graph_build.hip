@@ -139,18 +139,18 @@ __global__ __launch_bounds__(64 * kWaves) void k_build_graphs(
                       + (close ? 1 : 0);          // a ')' closes the level it came from
       const int rank = opens + __popcll(opened & below);   // index among the record's '('
 
-      // most recent '(' of my level inside this step (for ')'), and whether a later '('
-      // of the step has my level (for '(': only the last of a level is carried)
-      int mate = -1;
-      bool superseded = false;
+      // lanes of this step whose '(' has my level, as a 64-bit mask per lane: one compare and
+      // one select per open bracket of the step.  For a ')' the mate is the highest such
+      // lane below me; a '(' is superseded (not carried) if there is one above me.
+      unsigned long long same = 0;
       for (unsigned long long m = opened; m; m &= m - 1ull) {
         const int i = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
         const int level_i = __builtin_amdgcn_readlane(level, i);
-        if (level_i == level) {
-          if (close && i < lane) mate = i;
-          if (open && i > lane) superseded = true;
-        }
+        same |= level_i == level ? (1ull << i) : 0ull;
       }
+      const unsigned long long lower = same & below;
+      const int mate = (close && lower) ? 63 - __builtin_clzll(lower) : -1;
+      const bool superseded = open && (same & ~upto) != 0;
       const int mate_rank = __shfl(rank, mate < 0 ? 0 : mate, 64);
       __builtin_amdgcn_wave_barrier();
       int partner = -1, partner_rank = 0;
