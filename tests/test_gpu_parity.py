@@ -588,3 +588,28 @@ def test_build_csr_and_encode_are_graph_capturable(gpu_encoder):
         graph.replay()
         torch.cuda.synchronize()
     assert torch.equal(out, want)
+
+
+def test_context_rows_are_dropped_the_same_way_in_every_micro_batch(gpu_encoder, rouskin_records):
+    """Sliced records with context nucleotides (node_roles = 1): the multi-micro-batch path
+    (packed uploads, out_rows per batch, pinned-ring downloads) returns exactly what one
+    micro-batch returns, and only the core rows."""
+    from ginfinity_amd import RNA, GraphBuilder
+    windows = []
+    for record in rouskin_records[:160]:
+        if record.length >= 60:
+            windows.append(RNA(record.identifier, record.sequence, record.structure,
+                               start=record.length // 4, end=record.length // 4 + 30))
+    assert len(windows) > 50
+    shard = GraphBuilder(keep_paired_neighbours=True, context_hops=2).build_shard(windows)
+    assert int((shard.node_roles == 1).sum()) > 0
+    whole = gpu_encoder.encode_graphs(shard)
+    limit_nodes = max(shard.lengths) + 40
+    pieces = gpu_encoder.encode_graphs(shard, max_batch_nodes=limit_nodes,
+                                       max_batch_edges=6 * limit_nodes)
+    assert len(pieces) == len(whole) == len(windows)
+    for a, b in zip(pieces, whole):
+        assert a.shape == (30, 128) and a.tobytes() == b.tobytes()
+    via_records = gpu_encoder.encode_many(windows, keep_paired_neighbours=True, context_hops=2)
+    for a, b in zip(via_records, whole):
+        assert a.tobytes() == b.tobytes()
