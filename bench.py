@@ -73,7 +73,45 @@ def parse() -> argparse.Namespace:
                              "streams, else the library default 512)")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--cpu-seconds", type=float, default=12.0)
+    parser.add_argument("--spawn", action="store_true",
+                        help="go through the rank launcher even for --gpus 1 (world size 1 "
+                             "under torch.distributed.run, RCCL group created)")
     return parser.parse_args()
+
+
+def launch_ranks(args: argparse.Namespace) -> "NoReturn":
+    """``python bench.py --gpus N`` outside torchrun: start N fresh rank processes and relay
+    rank 0's line.  The reference's model is one process per shard under an external
+    scheduler (docs/GRAPH_PIPELINE.md:22-24); here the scheduler is torch.distributed.run,
+    one rank per GPU.  This process never touches HIP (``torch.cuda.device_count()`` does
+    not initialise the runtime) and never replaces itself: the ranks are children and
+    their exit status is ours."""
+    import socket
+    import subprocess
+
+    visible = torch.cuda.device_count()
+    if visible < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {visible} HIP device(s) visible; "
+              "refusing to report a smaller world as if it were the requested one",
+              file=sys.stderr)
+        raise SystemExit(3)
+    with socket.socket() as probe:
+        probe.bind(("127.0.0.1", 0))
+        port = probe.getsockname()[1]
+    passed = [a for a in sys.argv[1:] if a != "--spawn"]
+    command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), str(Path(__file__).resolve()), *passed]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes
+    done = subprocess.run(command, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [line for line in done.stdout.splitlines() if line.startswith("{")]
+    for line in (lines[-1:] if done.returncode == 0 else done.stdout.splitlines()):
+        print(line, flush=True)
+    if done.returncode == 0 and not lines:
+        print("bench.py: the ranks exited 0 without a result line", file=sys.stderr)
+        raise SystemExit(4)
+    raise SystemExit(done.returncode)
 
 
 def measured_traffic(kernel: str):
@@ -112,12 +150,18 @@ def cpu_baseline(seconds: float) -> dict:
 
 def main() -> None:
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "RANK" not in os.environ and (args.gpus > 1 or args.spawn):
+        launch_ranks(args)            # before anything touches the GPU; does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     # under torch.distributed.run (RANK set) the process group is always created, so the
     # RCCL path (barrier + MAX all-reduce) is the one exercised even at world size 1
     distributed = "RANK" in os.environ
+    if distributed and world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if distributed:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -248,6 +292,7 @@ def main() -> None:
                        "nodes_per_step": NODES, "edges_per_step": EDGES,
                        "shards_per_rank": POOL, "streams_per_gpu": lanes,
                        "layer_workgroups": layer_workgroups,
+                       "rccl_ranks": dist.get_world_size() if distributed else 0,
                        "parallelism": f"shard-parallel x{world}"},
             "roofline": roofline, "cpu_baseline": baseline, "kernels_ms": kernels,
         }))

@@ -50,3 +50,11 @@ def test_bench_line_one_stream_without_cpu_baseline():
     line = _run("--steps", "20", "--warmup", "4", "--streams", "1", "--no-cpu-baseline")
     assert line["cpu_baseline"] is None and line["steps"] == 20
     assert line["config"]["layer_workgroups"] == 512
+
+
+def test_bench_through_the_rank_launcher_world_size_one():
+    """`--spawn` = what `--gpus N>1` does: the parent starts torch.distributed.run, the one
+    rank creates the RCCL group, rank 0's line is relayed."""
+    line = _run("--gpus", "1", "--spawn", "--steps", "20", "--warmup", "4", "--no-cpu-baseline")
+    assert line["n_gpus"] == 1 and line["config"]["rccl_ranks"] == 1
+    assert line["value"] > 1e8 and line["cpu_baseline"] is None
