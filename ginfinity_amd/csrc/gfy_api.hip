@@ -40,6 +40,22 @@ void pack_b_fragments(const f16* w, int n_out, int k_in, f16* frag) {
                 8 * (lane >> 5) + j];
 }
 
+void pack_chain_fragments(const f16* w, int n_out, int k_in, f16* frag) {
+  const int blocks = n_out / 32, ksteps = k_in / 16;
+  for (int blk = 0; blk < blocks; ++blk)
+    for (int s = 0; s < ksteps; ++s)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int m = lane & 31, half = lane >> 5;
+        const int reg = (m & 3) + 4 * (m >> 3), row_half = (m >> 2) & 1;   // C/D row m
+        const int out_channel = 32 * blk + 16 * (reg >> 3) + 8 * row_half + (reg & 7);
+        for (int j = 0; j < 8; ++j) {
+          const int k = 16 * s + 8 * (j >> 2) + 4 * half + (j & 3);
+          frag[(((size_t)blk * ksteps + s) * 64 + lane) * 8 + j] =
+              w[(size_t)out_channel * k_in + k];
+        }
+      }
+}
+
 namespace {
 
 constexpr uint32_t kMagic = 0x31594647u;  // 'GFY1'
@@ -142,11 +158,12 @@ int gfy_encoder_create(const void* weight_pack_host, size_t bytes,
   Blob blob;
   // offsets first (pointers are fixed up after the single upload)
   struct LayerOff {
-    size_t table, w0, b0, alpha, shift, w1, b1, lg, lb;               // f16 mode
+    size_t table, w0, b0, alpha, shift, w1, b1, lg, lb, w1c, image;   // f16 mode
     size_t ftable, fw0, fb0, falpha, fshift, fw1, fb1, flg, flb;      // f32 mode
     float scale, one_plus_eps;
   };
-  size_t o_win = 0, o_bin = 0, o_wa = 0, o_ba = 0, o_wb = 0, o_bb = 0;
+  size_t o_win = 0, o_bin = 0, o_wa = 0, o_ba = 0, o_wb = 0, o_bb = 0, o_hchain = 0,
+         o_himage = 0;
   std::vector<LayerOff> lo(L);
 
   const float* w_in = rd.take((size_t)H * kInDim);
@@ -200,6 +217,9 @@ int gfy_encoder_create(const void* weight_pack_host, size_t bytes,
       for (size_t i = 0; i < tmp.size(); ++i) tmp[i] = rh(w1[i]);
       o.w1 = blob.reserve(tmp.size() * sizeof(f16));
       pack_b_fragments(tmp.data(), H, M, blob.at<f16>(o.w1));
+      o.w1c = blob.reserve(2 * tmp.size() * sizeof(f16));   // [W0 fragments | W1 chained]
+      std::memcpy(blob.at<f16>(o.w1c), blob.at<f16>(o.w0), tmp.size() * sizeof(f16));
+      pack_chain_fragments(tmp.data(), H, M, blob.at<f16>(o.w1c) + tmp.size());
       o.b0 = blob.reserve(M * sizeof(f16));
       o.alpha = blob.reserve(M * 4);
       o.shift = blob.reserve(M * 4);
@@ -220,6 +240,41 @@ int gfy_encoder_create(const void* weight_pack_host, size_t bytes,
         blob.at<f16>(o.b1)[c] = rh(b1[c]);
         blob.at<f16>(o.lg)[c] = rh(lg[c]);
         blob.at<f16>(o.lb)[c] = rh(lb[c]);
+      }
+      // LDS image of gine_layer3.inc, in the order its lanes read it: edge table, the
+      // -inf row of idle slots, alpha / shift / b0 as [block][lane half][register] of the
+      // 32x32 MFMA result, b1 / gamma / beta as [lane half][chunk][element] of the hidden
+      // state's register layout
+      o.image = blob.reserve(7680);
+      {
+        char* im = blob.at<char>(o.image);
+        std::memcpy(im, blob.at<char>(o.table), (size_t)kMaxEdgeTypes * H * sizeof(f16));
+        f16* ninf = reinterpret_cast<f16*>(im + 4096);
+        for (int c = 0; c < H; ++c) ninf[c] = (f16)(-INFINITY);
+        float* ia = reinterpret_cast<float*>(im + 4352);
+        float* is = reinterpret_cast<float*>(im + 4352 + 1024);
+        f16* ib0 = reinterpret_cast<f16*>(im + 4352 + 2048);
+        for (int b = 0; b < M / 32; ++b)
+          for (int half = 0; half < 2; ++half)
+            for (int reg = 0; reg < 16; ++reg) {
+              const int c = gemm_result_channel(b, half, reg);
+              const int at = (b * 2 + half) * 16 + reg;
+              ia[at] = blob.at<float>(o.alpha)[c];
+              is[at] = blob.at<float>(o.shift)[c];
+              ib0[at] = blob.at<f16>(o.b0)[c];
+            }
+        f16* ib1 = reinterpret_cast<f16*>(im + 4352 + 2048 + 512);
+        f16* ig = ib1 + H;
+        f16* ib = ig + H;
+        for (int half = 0; half < 2; ++half)
+          for (int ks = 0; ks < 8; ++ks)
+            for (int j = 0; j < 8; ++j) {
+              const int c = hidden_layout_channel(half, ks, j);
+              const int at = (half * 8 + ks) * 8 + j;
+              ib1[at] = blob.at<f16>(o.b1)[c];
+              ig[at] = blob.at<f16>(o.lg)[c];
+              ib[at] = blob.at<f16>(o.lb)[c];
+            }
       }
     } else {
       auto put = [&](const float* src, size_t n) {
@@ -274,6 +329,26 @@ int gfy_encoder_create(const void* weight_pack_host, size_t bytes,
       blob.at<f16>(o_ba)[c] = rh(ba[c]);
       blob.at<f16>(o_bb)[c] = rh(bbias[c]);
     }
+    // gine_layer3.inc: head.0 as plain fragments, head.2 chained behind it; biases in the
+    // orders the two results come out in
+    o_hchain = blob.reserve((size_t)2 * H * H * sizeof(f16));
+    std::memcpy(blob.at<f16>(o_hchain), blob.at<f16>(o_wa), (size_t)H * H * sizeof(f16));
+    pack_chain_fragments(tmp.data(), kOutDim, H, blob.at<f16>(o_hchain) + (size_t)H * H);
+    o_himage = blob.reserve(512);
+    {
+      f16* iba = blob.at<f16>(o_himage);
+      f16* ibb = iba + H;
+      for (int b = 0; b < H / 32; ++b)
+        for (int half = 0; half < 2; ++half)
+          for (int reg = 0; reg < 16; ++reg)
+            iba[(b * 2 + half) * 16 + reg] =
+                blob.at<f16>(o_ba)[gemm_result_channel(b, half, reg)];
+      for (int half = 0; half < 2; ++half)
+        for (int ks = 0; ks < 8; ++ks)
+          for (int j = 0; j < 8; ++j)
+            ibb[(half * 8 + ks) * 8 + j] =
+                blob.at<f16>(o_bb)[hidden_layout_channel(half, ks, j)];
+    }
   } else {
     o_wa = blob.reserve((size_t)H * H * 4);
     o_wb = blob.reserve((size_t)kOutDim * H * 4);
@@ -319,8 +394,11 @@ int gfy_encoder_create(const void* weight_pack_host, size_t bytes,
       d.b1 = H16(o.b1);
       d.ln_gamma = H16(o.lg);
       d.ln_beta = H16(o.lb);
+      d.w01_image = H16(o.w1c);
+      d.image3 = base + o.image;
     }
-    enc->f16.head = HeadF16{H16(o_wa), H16(o_ba), H16(o_wb), H16(o_bb)};
+    enc->f16.head = HeadF16{H16(o_wa), H16(o_ba), H16(o_wb), H16(o_bb), H16(o_hchain),
+                            base + o_himage};
   } else {
     enc->f32.w_in_t = F32p(o_win);
     enc->f32.b_in = F32p(o_bin);
@@ -367,6 +445,29 @@ int gfy_encoder_set_layer_workgroups(gfy_encoder* enc, int workgroups) {
               "gfy_encoder_set_layer_workgroups: %d outside 0..65536", workgroups);
   enc->layer_workgroups = workgroups;
   return GFY_OK;
+}
+
+int gfy_encoder_set_option(gfy_encoder* enc, int option, int value) {
+  clear_error();
+  GFY_REQUIRE(enc != nullptr, GFY_ERR_INVALID, "gfy_encoder_set_option: encoder is NULL");
+  switch (option) {
+    case GFY_OPT_LAYER_KERNEL:
+      GFY_REQUIRE(value == 2 || value == 3, GFY_ERR_INVALID,
+                  "gfy_encoder_set_option: GFY_OPT_LAYER_KERNEL must be 2 or 3 (got %d)", value);
+      enc->layer_kernel = value;
+      return GFY_OK;
+    case GFY_OPT_SEPARATE_HEAD:
+      GFY_REQUIRE(value == 0 || value == 1, GFY_ERR_INVALID,
+                  "gfy_encoder_set_option: GFY_OPT_SEPARATE_HEAD must be 0 or 1 (got %d)", value);
+      enc->separate_head = value;
+      return GFY_OK;
+    case GFY_OPT_TUNE:
+      enc->tune = value;
+      return GFY_OK;
+    default:
+      set_error("gfy_encoder_set_option: unknown option %d", option);
+      return GFY_ERR_INVALID;
+  }
 }
 
 int gfy_encoder_get_timing(gfy_encoder* enc, float* ms_host, int capacity, int* count) {

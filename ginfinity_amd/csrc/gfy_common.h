@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
 
 #include "../../include/gfy.h"
 
@@ -51,6 +52,27 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Runs `configure` once per HIP device (the calling thread's current device), thread-safe:
+// hipFuncSetAttribute is per device, and one process may drive several GPUs from several
+// threads (Ginfinity.load accepts "cuda:<i>").
+class PerDeviceOnce {
+ public:
+  template <typename F>
+  int run(F&& configure) {
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 256) return GFY_ERR_HIP;
+    std::lock_guard<std::mutex> guard(mutex_);
+    if ((done_[device >> 6] >> (device & 63)) & 1u) return GFY_OK;
+    const int rc = configure();
+    if (rc == GFY_OK) done_[device >> 6] |= 1ull << (device & 63);
+    return rc;
+  }
+
+ private:
+  std::mutex mutex_;
+  unsigned long long done_[4] = {};
+};
+
 // ---- fp16 layer parameters on the device (see gine_f16.hip for the layouts) ------
 struct LayerF16 {
   const f16* edge_table;  // [kMaxEdgeTypes][128]  R(W_edge[:,t] + b_edge), rows >= edge_dim zero
@@ -63,6 +85,11 @@ struct LayerF16 {
   const f16* b1;          // [128]
   const f16* ln_gamma;    // [128]
   const f16* ln_beta;     // [128]
+  // third-generation layer kernel (gine_layer3.inc)
+  const f16* w01_image;   // 128 KB: mlp.0.weight fragments | mlp.4.weight fragments for a B
+                          // operand taken from the first product's result (pack_chain_fragments)
+  const void* image3;     // 7,680-byte LDS image: edge table + -inf row, alpha, shift, b0,
+                          // b1, gamma, beta in the orders the lanes read them
 };
 
 struct HeadF16 {
@@ -70,6 +97,8 @@ struct HeadF16 {
   const f16* ba;       // [128]
   const f16* wb_frag;  // head.2.weight fragments
   const f16* bb;       // [128]
+  const f16* w_chain;  // gine_layer3.inc: head.0 fragments (32 KB) | head.2 chained (32 KB)
+  const void* image3;  // 512-byte LDS image: ba (GEMM result order) | bb (hidden order)
 };
 
 struct ModelF16 {
@@ -117,6 +146,9 @@ struct gfy_encoder {
   // 1 .. layers-1: an event between two dependent kernels costs ~2.5 us of stream time that
   // rocprof's kernel durations do not contain.
   int layer_workgroups = 0;   // gfy_encoder_set_layer_workgroups (0 = default)
+  int layer_kernel = 3;       // GFY_OPT_LAYER_KERNEL: 3 = gine_layer3.inc, 2 = gine_layer.inc
+  int separate_head = 0;      // GFY_OPT_SEPARATE_HEAD
+  int tune = 0;               // GFY_OPT_TUNE: diagnostic schedule switches of gine_layer3.inc
   int timing = 0;
   hipEvent_t events[gfy::kMaxLayers + 3] = {};
   mutable int events_recorded = 0;
@@ -202,5 +234,17 @@ __device__ __forceinline__ void dma_wait_all() {
 // W[n_out][k_in] (row-major fp16) -> MFMA 32x32x16 B-operand fragment order:
 // frag[(ntile * ksteps + ks) * 64 + lane][8] = W[32*ntile + (lane & 31)][16*ks + 8*(lane >> 5) + j]
 void pack_b_fragments(const f16* w, int n_out, int k_in, f16* frag);
+
+// Fragments of the SECOND product of a chain (gine_layer3.inc): its B operand is the first
+// product's 32x32 result converted in place, so k-step s holds, in element j of lane half h,
+// input channel 16 s + 8 (j >> 2) + 4 h + (j & 3); and its rows are dealt so that the result
+// lands in the hidden-state layout (lane half h, register i of block blk = output channel
+// 32 blk + 16 (i >> 3) + 8 h + (i & 7)).
+void pack_chain_fragments(const f16* w, int n_out, int k_in, f16* frag);
+// index helpers shared by the constant images
+inline int gemm_result_channel(int block, int half, int reg) {   // 32x32 C/D layout
+  return 32 * block + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+}
+inline int hidden_layout_channel(int half, int ks, int j) { return 16 * ks + 8 * half + j; }
 
 }  // namespace gfy

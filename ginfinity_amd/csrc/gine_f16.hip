@@ -387,6 +387,7 @@ __global__ __launch_bounds__(256) void k_copy_rows_f16(const f16* __restrict__ s
 }
 
 #include "gine_layer.inc"
+#include "gine_layer3.inc"
 
 int persistent_grid(int num_tiles) {
   int g = num_tiles < 256 ? num_tiles : 256;
@@ -418,9 +419,31 @@ extern "C" int gfy_debug_stamps(unsigned long long* host /*[256][16]*/, int rese
 static size_t h_buffer_bytes(int64_t n) {
   return align_up((size_t)(n + 2 * kTile) * kHidden * sizeof(f16), 256);
 }
-// ... plus one plan per 32-node tile (gine_layer.inc)
+// ... plus one plan per 32-node tile (gine_layer3.inc; gine_layer.inc's are larger)
 static size_t plan_bytes(int64_t n) {
+  static_assert(kPlanBytes >= kP3Bytes && kT2 == kT3, "one plan area serves both generations");
   return align_up((size_t)((n + kT2 - 1) / kT2) * kPlanBytes, 256);
+}
+
+// > 64 KB of dynamic LDS needs an opt-in per kernel and per DEVICE (a process may drive
+// several GPUs, from several threads)
+static PerDeviceOnce g_layer_lds_opt_in;
+static int opt_in_layer_lds() {
+  return g_layer_lds_opt_in.run([]() -> int {
+#define GFY_OPT_IN(kernel, bytes)                                                          \
+  GFY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel),                \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes))
+    GFY_OPT_IN((k_gine_layer_f16<true, false>), k2Bytes);
+    GFY_OPT_IN((k_gine_layer_f16<false, false>), k2Bytes);
+    GFY_OPT_IN((k_gine_layer_f16<true, true>), k2Bytes);
+    GFY_OPT_IN((k_gine_layer_f16<false, true>), k2Bytes);
+    GFY_OPT_IN((k_gine_layer3_f16<true, false>), k3Bytes);
+    GFY_OPT_IN((k_gine_layer3_f16<false, false>), k3Bytes);
+    GFY_OPT_IN((k_gine_layer3_f16<true, true>), k3Bytes);
+    GFY_OPT_IN((k_gine_layer3_f16<false, true>), k3Bytes);
+#undef GFY_OPT_IN
+    return GFY_OK;
+  });
 }
 size_t encode_f16_workspace_bytes(int64_t n, int64_t /*e*/) {
   return 2 * h_buffer_bytes(n) + plan_bytes(n);
@@ -445,51 +468,52 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
   const int num_tiles = (int)((n + kTile - 1) / kTile);   // stand-alone head kernel
   const int grid = persistent_grid(num_tiles);
   const int layer_tiles = (int)((n + kT2 - 1) / kT2);
-  int layer_cap = enc->layer_workgroups > 0 ? enc->layer_workgroups : 512;   // 512 = two per CU
-  if (const char* g = getenv("GFY_LAYER_GRID")) layer_cap = atoi(g);          // diagnostic
-  int layer_grid = layer_tiles < layer_cap ? layer_tiles : layer_cap;
-  layer_grid = (layer_grid + 7) & ~7;                        // whole XCD rounds
+  const bool third = enc->layer_kernel != 2;
+  int layer_grid;
+  if (third) {
+    // one tile per wave, eight per workgroup, XCD x = workgroups x, x + 8, ... (gine_layer3.inc)
+    layer_grid = 8 * ((layer_tiles + 8 * kWaves3 - 1) / (8 * kWaves3));
+  } else {
+    const int layer_cap = enc->layer_workgroups > 0 ? enc->layer_workgroups : 512;   // two per CU
+    layer_grid = layer_tiles < layer_cap ? layer_tiles : layer_cap;
+    layer_grid = (layer_grid + 7) & ~7;                      // whole XCD rounds
+  }
 
   const int64_t items = n * 16;
   enc->mark(s, 0);
   {
     const int64_t blocks = (items + 255) / 256;
     const int linear_blocks = (int)(blocks > 2048 ? 2048 : blocks);
-    if (tap_stage != 0)   // + tile plans, once for all layers, in the same launch
-      k_encode_setup<<<layer_tiles + linear_blocks, 256, 0, s>>>(
-          x, enc->f16.w_in, enc->f16.b_in, ha, (int)n, row_ptr, col, typ, plans, layer_tiles);
-    else
+    if (tap_stage == 0)
       k_input_linear_f16<<<linear_blocks, 256, 0, s>>>(x, enc->f16.w_in, enc->f16.b_in, ha,
                                                        (int)n);
+    else if (third)   // + tile plans, once for all layers, in the same launch
+      k_encode_setup3<<<layer_tiles + linear_blocks, 256, 0, s>>>(
+          x, enc->f16.w_in, enc->f16.b_in, ha, (int)n, row_ptr, col, typ, plans, layer_tiles);
+    else
+      k_encode_setup<<<layer_tiles + linear_blocks, 256, 0, s>>>(
+          x, enc->f16.w_in, enc->f16.b_in, ha, (int)n, row_ptr, col, typ, plans, layer_tiles);
   }
   enc->mark(s, 1);
   const int stop = tap_stage >= 0 ? tap_stage : enc->layers;
-  static bool lds_opt_in = false;   // > 64 KB of dynamic LDS needs an explicit opt-in
-  if (!lds_opt_in) {
-    GFY_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&k_gine_layer_f16<true, false>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, k2Bytes));
-    GFY_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&k_gine_layer_f16<false, false>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, k2Bytes));
-    GFY_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&k_gine_layer_f16<true, true>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, k2Bytes));
-    GFY_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&k_gine_layer_f16<false, true>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, k2Bytes));
-    lds_opt_in = true;
-  }
+  if (const int rc = opt_in_layer_lds()) return rc;
   // fp16 output of a full encode: the last layer's launch runs the head as well
-  // (GFY_SEPARATE_HEAD=1 keeps the stand-alone head kernel: A/B runs and parity tests)
-  const bool fuse_head = tap_stage < 0 && out_dtype == GFY_F16 && stop > 0 && n >= kT2 &&
-                         !getenv("GFY_SEPARATE_HEAD");
+  // (GFY_OPT_SEPARATE_HEAD keeps the stand-alone head kernel: A/B runs and parity tests)
+  const bool fuse_head = tap_stage < 0 && out_dtype == GFY_F16 && stop > 0 &&
+                         (third || n >= kT2) && !enc->separate_head;
   for (int l = 0; l < stop; ++l) {
     const bool with_head = fuse_head && l == stop - 1;
 #define GFY_LAUNCH_LAYER(RES, HEAD)                                                          \
-  k_gine_layer_f16<RES, HEAD><<<layer_grid, kThreads2, k2Bytes, s>>>(                        \
-      enc->f16.layer[l], ha, hb, row_ptr, col, typ, plans, (int)n, layer_tiles, enc->f16.head, \
-      out_rows, (f16*)out, normalise)
+  do {                                                                                       \
+    if (third)                                                                               \
+      k_gine_layer3_f16<RES, HEAD><<<layer_grid, kThreads3, k3Bytes, s>>>(                   \
+          enc->f16.layer[l], ha, hb, row_ptr, col, typ, plans, (int)n, layer_tiles,          \
+          enc->f16.head, out_rows, (f16*)out, normalise, enc->tune);                         \
+    else                                                                                     \
+      k_gine_layer_f16<RES, HEAD><<<layer_grid, kThreads2, k2Bytes, s>>>(                    \
+          enc->f16.layer[l], ha, hb, row_ptr, col, typ, plans, (int)n, layer_tiles,          \
+          enc->f16.head, out_rows, (f16*)out, normalise);                                    \
+  } while (0)
     if (enc->residual && with_head) GFY_LAUNCH_LAYER(true, true);
     else if (enc->residual) GFY_LAUNCH_LAYER(true, false);
     else if (with_head) GFY_LAUNCH_LAYER(false, true);

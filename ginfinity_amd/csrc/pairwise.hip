@@ -432,6 +432,18 @@ constexpr int kPairLds = kBuffers * kRowBytes + kTermSlots * kTermBytes;   // ro
 
 size_t pairwise_workspace_bytes(int64_t n, int64_t m) { return carve(nullptr, n, m).bytes; }
 
+// > 64 KB of dynamic LDS: opt in once per device, thread-safe (gfy_common.h)
+static PerDeviceOnce g_pairwise_lds_opt_in;
+static int opt_in_pairwise_lds() {
+  return g_pairwise_lds_opt_in.run([]() -> int {
+    GFY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kPairLds));
+    GFY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kPairLds));
+    return GFY_OK;
+  });
+}
+
 int launch_pairwise_nearest(const void* a, int64_t n, const void* b, int64_t m,
                             int metric, int64_t exclude_offset, float* best_val,
                             int32_t* best_idx, void* ws, size_t ws_bytes,
@@ -459,14 +471,7 @@ int launch_pairwise_nearest(const void* a, int64_t n, const void* b, int64_t m,
   p.chunk_rows = w.chunk_rows;
   p.part_val = w.part_val;
   p.part_idx = w.part_idx;
-  static bool lds_opt_in = false;
-  if (!lds_opt_in) {
-    GFY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise<false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kPairLds));
-    GFY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise<true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kPairLds));
-    lds_opt_in = true;
-  }
+  if (const int rc = opt_in_pairwise_lds()) return rc;
   k_pairwise<false><<<w.blocks_a * w.chunks, kThreads, kPairLds, s>>>(p);
   k_nearest_finish<<<(int)((n + 255) / 256), 256, 0, s>>>(
       w.part_val, w.part_idx, w.a_term, n, w.chunks, metric, best_val, best_idx);
@@ -502,8 +507,7 @@ int launch_pairwise_dense(const void* a, int64_t n, const void* b, int64_t m,
   p.chunks = 1;
   p.chunk_rows = (m + kTileB - 1) / kTileB * kTileB;
   p.dense = out;
-  GFY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, kPairLds));
+  if (const int rc = opt_in_pairwise_lds()) return rc;
   k_pairwise<true><<<p.blocks_a, kThreads, kPairLds, s>>>(p);
   GFY_CHECK_HIP(hipGetLastError());
   return GFY_OK;

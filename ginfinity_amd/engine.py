@@ -246,6 +246,12 @@ class DeviceEncoder:
         native.check(self._lib.gfy_encoder_set_layer_workgroups(
             self._handle, int(workgroups)), "gfy_encoder_set_layer_workgroups")
 
+    def set_option(self, option: int, value: int) -> None:
+        """Diagnostic switches of include/gfy.h (``native.GFY_OPT_*``): which generation
+        of the layer kernel runs, head fused into the last layer launch or not."""
+        native.check(self._lib.gfy_encoder_set_option(
+            self._handle, int(option), int(value)), "gfy_encoder_set_option")
+
     def set_timing(self, enabled: bool | int) -> None:
         """True / 1: an event after every launch; 2: none between layer launches
         1 .. L-1, whose mean is reported (agrees with rocprof's kernel durations)."""

@@ -176,6 +176,17 @@ int gfy_encoder_set_timing(gfy_encoder* encoder, int enable);
  * 678 M nodes/s; one encode at a time loses: 146 -> 183 us).  Rounded up to a multiple
  * of 8; results do not depend on it. */
 int gfy_encoder_set_layer_workgroups(gfy_encoder* encoder, int workgroups);
+
+/* Diagnostic options of one encoder (no reference counterpart; results within the stated
+ * tolerances for every setting).  Set between encodes, never read from the environment.
+ *   GFY_OPT_LAYER_KERNEL   3 (default): one wave per 32-node tile, weights in LDS, activations
+ *                          in registers (csrc/gine_layer3.inc); 2: the previous generation
+ *                          (csrc/gine_layer.inc), kept for A/B measurements
+ *   GFY_OPT_SEPARATE_HEAD  1: head + normalise as its own launch even for fp16 output
+ *   GFY_OPT_TUNE           bit mask of schedule experiments inside the layer kernel (0 =
+ *                          the shipped schedule); never changes a result                    */
+enum gfy_option { GFY_OPT_LAYER_KERNEL = 1, GFY_OPT_SEPARATE_HEAD = 2, GFY_OPT_TUNE = 3 };
+int gfy_encoder_set_option(gfy_encoder* encoder, int option, int value);
 int gfy_encoder_get_timing(gfy_encoder* encoder, float* ms_host, int capacity,
                            int* count);
 

@@ -438,22 +438,31 @@ def test_abi_rejects_oversized_and_undersized_requests(gpu_encoder):
     assert status == native.GFY_ERR_UNSUPPORTED
 
 
-def test_fused_head_equals_standalone_head(gpu_encoder, monkeypatch):
+def test_fused_head_equals_standalone_head(gpu_encoder):
     """fp16 output runs the head inside the last layer's launch; the stand-alone
-    head kernel (GFY_SEPARATE_HEAD=1, also the f32/f64-output path) must give the
+    head kernel (GFY_OPT_SEPARATE_HEAD, also the f32/f64-output path) must give the
     same bytes — with and without dropped context rows, ragged last tile included."""
-    from ginfinity_amd import synthetic
-    for shard in (synthetic.arbitrary_shard(3, nodes=10_007, edges=40_000),   # context rows
-                  synthetic.roofline_shard(5, records=2, length=1_000)):      # all core
-        monkeypatch.delenv("GFY_SEPARATE_HEAD", raising=False)
-        fused = np.concatenate(gpu_encoder.encode_graphs(shard))
-        monkeypatch.setenv("GFY_SEPARATE_HEAD", "1")
-        alone = np.concatenate(gpu_encoder.encode_graphs(shard))
-        assert fused.dtype == np.float16 and fused.shape == alone.shape
-        assert np.array_equal(fused.view(np.uint16), alone.view(np.uint16))
-        as_f32 = np.concatenate(gpu_encoder.encode_graphs(shard, embedding_dtype=np.float32))
-        monkeypatch.delenv("GFY_SEPARATE_HEAD")
-        assert _maxabs(as_f32, fused) <= 6e-4    # one fp16 rounding of a unit-norm row
+    from ginfinity_amd import _native as native, synthetic
+    engine = gpu_encoder._engine
+    try:
+        for shard in (synthetic.arbitrary_shard(3, nodes=10_007, edges=40_000),   # context rows
+                      synthetic.roofline_shard(5, records=2, length=1_000)):      # all core
+            engine.set_option(native.GFY_OPT_SEPARATE_HEAD, 0)
+            fused = np.concatenate(gpu_encoder.encode_graphs(shard))
+            engine.set_option(native.GFY_OPT_SEPARATE_HEAD, 1)
+            alone = np.concatenate(gpu_encoder.encode_graphs(shard))
+            assert fused.dtype == np.float16 and fused.shape == alone.shape
+            # same rounding points; the fused head takes head.2's B operand straight from
+            # head.0's MFMA result, i.e. with the 16 channels of a k-step arranged differently
+            # inside the instruction: last-bit flips of o on a few elements, nothing else
+            flips = float(np.mean(fused.view(np.uint16) != alone.view(np.uint16)))
+            print(f"fused vs stand-alone head: {flips:.2e} of elements differ, "
+                  f"max {_maxabs(fused, alone):.2e}")
+            assert flips < 2e-3 and _maxabs(fused, alone) <= 2.5e-4
+            as_f32 = np.concatenate(gpu_encoder.encode_graphs(shard, embedding_dtype=np.float32))
+            assert _maxabs(as_f32, fused) <= 6e-4    # one fp16 rounding of a unit-norm row
+    finally:
+        engine.set_option(native.GFY_OPT_SEPARATE_HEAD, 0)
 
 
 def _plan_boundary_shard():
@@ -524,7 +533,7 @@ def test_tile_plan_limits_against_oracle(gpu_encoder, oracle_weights):
         assert _maxabs(h, ref) < 0.06, stage
 
 
-def test_normalise_is_the_float64_quotient_rounded_once(gpu_encoder, monkeypatch):
+def test_normalise_is_the_float64_quotient_rounded_once(gpu_encoder):
     """api.py:250-259: o / max(|o|, 1e-12) in float64, ONE rounding to fp16.  The kernels
     take an fp32 shortcut wherever it provably rounds the same way; check all 7.7 M
     values of a config-3 shard bit for bit, fused and stand-alone head."""
@@ -537,28 +546,48 @@ def test_normalise_is_the_float64_quotient_rounded_once(gpu_encoder, monkeypatch
     wide = raw.astype(np.float64)
     norm = np.maximum(np.sqrt((wide * wide).sum(axis=1, keepdims=True)), 1e-12)
     want = (wide / norm).astype(np.float16)
-    for separate in (False, True):
-        if separate:
-            monkeypatch.setenv("GFY_SEPARATE_HEAD", "1")
-        got = engine.encode(x, csr, normalise=True).cpu().numpy()
-        assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), separate
+    from ginfinity_amd import _native as native
+    try:
+        for separate in (0, 1):
+            engine.set_option(native.GFY_OPT_SEPARATE_HEAD, separate)
+            if separate:   # the stand-alone head has its own raw output to be measured against
+                raw = engine.encode(x, csr, normalise=False).cpu().numpy()
+                wide = raw.astype(np.float64)
+                norm = np.maximum(np.sqrt((wide * wide).sum(axis=1, keepdims=True)), 1e-12)
+                want = (wide / norm).astype(np.float16)
+            got = engine.encode(x, csr, normalise=True).cpu().numpy()
+            assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), separate
+    finally:
+        engine.set_option(native.GFY_OPT_SEPARATE_HEAD, 0)
 
 
-def test_layer_workgroup_cap_does_not_change_results(gpu_encoder):
-    """gfy_encoder_set_layer_workgroups is a scheduling knob: 8, 256 and the default 512
-    workgroups must give the same bytes (more tiles per workgroup, other tile -> XCD map)."""
-    from ginfinity_amd import synthetic
+def test_layer_kernel_generations_agree(gpu_encoder):
+    """GFY_OPT_LAYER_KERNEL: the one-wave-per-tile kernel (3, default) against the previous
+    generation (2).  Same rounding points; the k order inside the second product's MFMAs
+    differs, so a few last-bit flips are allowed and nothing else.  Under generation 2
+    gfy_encoder_set_layer_workgroups is a scheduling knob only: same bytes for 8 / 256 / 512."""
+    from ginfinity_amd import _native as native, synthetic
     shard = synthetic.roofline_shard(4, records=3, length=2000)
     engine = gpu_encoder._engine
     x, ei, et = _device_inputs(gpu_encoder, shard)
     csr = engine.build_csr(ei, et, shard.node_count)
-    default = engine.encode(x, csr).cpu().numpy()
+    third = engine.encode(x, csr).cpu().numpy()
+    hidden3 = engine.hidden(x, csr, 1).cpu().numpy()
     try:
+        engine.set_option(native.GFY_OPT_LAYER_KERNEL, 2)
+        second = engine.encode(x, csr).cpu().numpy()
+        hidden2 = engine.hidden(x, csr, 1).cpu().numpy()
         for cap in (8, 256):
             engine.set_layer_workgroups(cap)
-            np.testing.assert_array_equal(engine.encode(x, csr).cpu().numpy(), default)
+            np.testing.assert_array_equal(engine.encode(x, csr).cpu().numpy(), second)
     finally:
         engine.set_layer_workgroups(0)
+        engine.set_option(native.GFY_OPT_LAYER_KERNEL, 3)
+    flips = float(np.mean(hidden3 != hidden2))
+    print(f"layer 0: generation 3 vs 2: {flips:.5f} of elements differ, "
+          f"max {_maxabs(hidden3, hidden2):.5f}; outputs max {_maxabs(third, second):.2e}")
+    assert flips < 0.02 and _maxabs(hidden3, hidden2) < 0.02
+    assert _maxabs(third, second) <= 1e-3
 
 
 def test_build_csr_and_encode_are_graph_capturable(gpu_encoder):

@@ -46,6 +46,8 @@ int main(int argc, char** argv) {
   }
   gfy_encoder* enc = nullptr;
   GK(gfy_encoder_create(pack.data(), bytes, GFY_F16, 0, &enc));
+  if (getenv("GFY_BENCH_TUNE")) GK(gfy_encoder_set_option(enc, GFY_OPT_TUNE, atoi(getenv("GFY_BENCH_TUNE"))));
+  if (getenv("GFY_BENCH_KERNEL2")) GK(gfy_encoder_set_option(enc, GFY_OPT_LAYER_KERNEL, 2));
   // graph: records of L nodes: backbone both ways, skip2 both ways, random matching both ways
   const int64_t recs = N / L;
   std::vector<int32_t> src, dst; std::vector<uint8_t> typ;
@@ -142,6 +144,33 @@ int main(int argc, char** argv) {
     gfy_debug_stamps(&st[0][0], 0);
     double sum[16] = {0};
     for (int b = 0; b < 256; ++b) for (int k = 0; k < 16; ++k) sum[k] += (double)st[b][k];
+    if (!getenv("GFY_BENCH_KERNEL2")) {   // third-generation kernel: one wave per tile
+      const double plain = sum[11], headed = sum[13], all = plain + headed;
+      const char* names[10] = {"plan+own rows (hop 1)", "far rows DMA + wait (hop 2)", "barrier 1",
+                               "gather", "W0 over own stage + barrier 2", "GEMM1 + BatchNorm",
+                               "W1 wait + barrier 3", "GEMM2", "LayerNorm + store", "head + normalise"};
+      printf("layer3 phases, shader cycles per launch (wave 0 of each workgroup, mean):\n");
+      for (int k = 0; k < 9; ++k) printf("  %-28s %8.0f\n", names[k], sum[k] / all);
+      printf("  %-28s %8.0f (last launch only)\n", names[9], sum[9] / headed);
+      printf("  GEMM1 split: MFMA blocks %.0f | epilogues %.0f\n", sum[14] / all, sum[15] / all);
+      printf("  whole wave: %.0f cycles (plain layer), %.0f (with head)\n", sum[10] / plain, sum[12] / headed);
+      static unsigned long long real[512][2];
+      gfy_debug_real(&real[0][0]);
+      unsigned long long b0 = ~0ull, b1 = 0, e0 = ~0ull, e1 = 0;
+      int used = 0;
+      for (int b = 0; b < 512; ++b) {
+        if (!real[b][1]) continue;
+        ++used;
+        b0 = real[b][0] < b0 ? real[b][0] : b0; b1 = real[b][0] > b1 ? real[b][0] : b1;
+        e0 = real[b][1] < e0 ? real[b][1] : e0; e1 = real[b][1] > e1 ? real[b][1] : e1;
+      }
+      if (used)
+        printf("last layer launch, real time (100 MHz): %d workgroups, first start -> last start %.2f us, "
+               "first end %.2f us, last end %.2f us after the first start\n",
+               used, (b1 - b0) / 100.0, (e0 - b0) / 100.0, (e1 - b0) / 100.0);
+      gfy_encoder_destroy(enc);
+      return 0;
+    }
     {
       const double launches = reps * 4.0 * 256;   // 4 layers, first 256 workgroups
       double tmax = 0, tmin = 1e30;

@@ -134,6 +134,52 @@ __global__ __launch_bounds__(512) void k_mfma_lds(const f16* w, float* out, int 
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+// (4b) the same with the reads of block b+1 issued one per MFMA of block b (pinned order)
+__global__ __launch_bounds__(512) void k_mfma_lds_pipelined(const f16* w, float* out, int iters,
+                                                             unsigned long long* cyc) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  for (int i = threadIdx.x; i < 4096; i += blockDim.x)
+    reinterpret_cast<f16x8*>(smem)[i] = reinterpret_cast<const f16x8*>(w)[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const f16x8* frag = reinterpret_cast<const f16x8*>(smem) + lane;
+  f16x8 z[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[k][j] = (f16)(0.01f * ((lane + k + j) % 17));
+  f32x16 total = {0};
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+    f16x8 cur[8], nxt[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) cur[ks] = frag[ks * 64];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      f32x16 acc = {0};
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        if (b < 7) nxt[ks] = frag[((b + 1) * 8 + ks) * 64];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[ks], z[ks], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one DS read
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+      }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) cur[ks] = nxt[ks];
+      total += acc;
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) s += total[j];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
 int main() {
   // ---- 1, 2
   const int n = 1 << 24;
@@ -207,6 +253,19 @@ int main() {
     for (int i = 0; i < 256; ++i) m += cyc[i];
     printf("MFMA with A from LDS (512 threads, 154 KB LDS, 2 waves/SIMD): %.1f cycles per MFMA per wave\n",
            m / 256 / 50 / 64);
+  }
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mfma_lds_pipelined),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  for (int threads = 256; threads <= 512; threads += 256) {
+    k_mfma_lds_pipelined<<<256, threads, lds>>>(dw, fo, 50, dcyc);
+    CHECK(hipGetLastError());
+    CHECK(hipDeviceSynchronize());
+    unsigned long long cyc[256];
+    CHECK(hipMemcpy(cyc, dcyc, sizeof cyc, hipMemcpyDeviceToHost));
+    double m = 0;
+    for (int i = 0; i < 256; ++i) m += cyc[i];
+    printf("  reads pipelined one block ahead, %d waves per SIMD: %.1f cycles per MFMA per wave\n",
+           threads / 256, m / 256 / 50 / 64);
   }
   return 0;
 }
