@@ -2,29 +2,36 @@
 shards (BASELINE.json configs[2]), fp16 model, inputs resident in HBM.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
-        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One step = one pass of the hot path over one shard: COO→CSR build (5 launches),
-per-encode setup (tile plans + input Linear, 1 launch), 4 fused GINE layer launches
-the last of which also runs head + float64 L2 normalise, embeddings left on the
-device.  Multi-GPU: shards are independent, every rank encodes
-its own shards, there is no data-path collective ("weak" scaling); the only
-communication is the barrier and the MAX-reduction of the elapsed time.
+``--gpus N`` with N > 1 (or ``--spawn``) outside torch.distributed.run: this process starts
+the N ranks itself (``python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1 ...``) before anything touches HIP, relays rank 0's line and exits
+with the ranks' status.  Under torch.distributed.run it is one rank.
+
+One step = one pass of the hot path over one shard: COO→CSR build, per-encode setup (tile
+plans + input Linear, 1 launch), 4 fused GINE layer launches the last of which also runs
+head + float64 L2 normalise, embeddings left on the device.  Multi-GPU: shards
+are independent, every rank encodes its own shards, there is no data-path collective
+("weak" scaling); the only communication is the barrier and the MAX-reduction of the
+elapsed time.
 
 Before the W warm-up steps the script runs the same steps untimed for 0.25 s
 (GFY_BENCH_SETTLE_S): set-up, so that every pre-bound step exists and the part has
-reached its working clocks whatever K and W are (K=50/W=5: 552 -> 671 M nodes/s;
-K=1000/W=100: 672 -> 683).  Then W warm-up steps, barrier + synchronize, EXACTLY K
-timed steps, synchronize, MAX over ranks.
+reached its working clocks whatever K and W are.  Then W warm-up steps, barrier +
+synchronize, EXACTLY K timed steps, synchronize, MAX over ranks.
 
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   roofline      dominant kernel (k_gine_layer_f16): algorithmic bytes per launch
-                (512·N + 9·E + layer weights) ÷ its mean
-                duration (layers 1-3: the launches without the fused head) measured
-                with one HIP event pair around those three launches on the launch stream
-  cpu_baseline  oracle/gine_torch.py (the reference's aten op sequence) timed on
-                this box's host cores on the same workload — N=1 only.
+                (512·N + 9·E + layer weights) ÷ its mean duration, measured
+                with HIP events on the launch streams IN THE TIMED CONFIGURATION (all
+                streams in flight); `isolated` repeats it one shard at a time; `traffic`
+                = HBM bytes per launch from the committed PMC passes, only while they
+                were taken from the kernel source as it is now (else null)
+  distance      BASELINE configs[3]: all-pairs nearest over 1M x 128 fp16 rows, fraction
+                of the dense fp16 MFMA peak (N=1 only)
+  cpu_baseline  oracle/gine_torch.py (the reference's aten op sequence) timed on this
+                box's host cores on the same workload, best of several thread counts —
+                N=1 only.
 """
 from __future__ import annotations
 
@@ -68,9 +75,8 @@ def parse() -> argparse.Namespace:
     parser.add_argument("--warmup", type=int, default=100)
     parser.add_argument("--streams", type=int, default=4,
                         help="independent shards in flight per GPU (HIP streams)")
-    parser.add_argument("--layer-workgroups", type=int, default=0,
-                        help="cap of the layer kernel's grid (0 = 256 with three or more "
-                             "streams, else the library default 512)")
+    parser.add_argument("--distance-rows", type=int, default=1_000_000,
+                        help="rows of the all-pairs nearest leg (0 = skip it)")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--cpu-seconds", type=float, default=12.0)
     parser.add_argument("--spawn", action="store_true",
@@ -114,20 +120,39 @@ def launch_ranks(args: argparse.Namespace) -> "NoReturn":
     raise SystemExit(done.returncode)
 
 
+KERNEL_SOURCES = ("ginfinity_amd/csrc/gine_layer.inc", "ginfinity_amd/csrc/gine_f16.hip",
+                  "ginfinity_amd/csrc/gfy_common.h")
+
+
+def kernel_source_sha16() -> str:
+    """Fingerprint of the sources the dominant kernel is compiled from."""
+    import hashlib
+    digest = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        digest.update((ROOT / name).read_bytes())
+    return digest.hexdigest()[:16]
+
+
 def measured_traffic(kernel: str):
-    """HBM bytes per launch of ``kernel`` from the committed PMC passes
-    (profiles/r01c_traffic_pmc.json: rocprofv3 FETCH_SIZE/WRITE_SIZE, gfx950
-    half-count correction applied).  Counter passes cannot run inside this script;
-    None if the file is absent."""
-    path = ROOT / "profiles" / "r01c_traffic_pmc.json"
-    try:
-        return json.loads(path.read_text())["kernels"][kernel]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
+    """HBM bytes per launch of ``kernel`` from the committed PMC passes (rocprofv3
+    FETCH_SIZE / WRITE_SIZE, gfx950 half-count correction applied; tools/profile_round.sh +
+    tools/pmc_summary.py).  Counter passes cannot run inside this script, so the figure is
+    only reported while the summary was taken from the kernel source as it is now."""
+    newest = sorted((ROOT / "profiles").glob("r*_traffic_pmc.json"))
+    for path in reversed(newest):
+        try:
+            summary = json.loads(path.read_text())
+            if summary.get("kernel_source_sha16") != kernel_source_sha16():
+                continue
+            return summary["kernels"][kernel]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def cpu_baseline(seconds: float) -> dict:
-    """Reference-equivalent CPU encode (same aten ops) on the same workload."""
+    """Reference-equivalent CPU encode (same aten ops) on the same workload, at the best of
+    several torch thread counts (oversubscribing a 256-cpu host is slower than 8 threads)."""
     from ginfinity_amd import synthetic
     from ginfinity_amd.weights import load_checkpoint
     from oracle import gine_torch
@@ -135,17 +160,48 @@ def cpu_baseline(seconds: float) -> dict:
     params = gine_torch.prepare(load_checkpoint().state)
     shard = synthetic.roofline_shard(0)
     arrays = (shard.node_features, shard.edge_index, shard.edge_types)
-    gine_torch.encode(params, *arrays)                       # warm
-    done, began = 0, time.perf_counter()
-    while done < 3 or time.perf_counter() - began < seconds:
-        gine_torch.encode(params, *arrays)
-        done += 1
-    elapsed = time.perf_counter() - began
-    return {"value": done * NODES / elapsed, "unit": "nodes/s",
-            "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{done} encodes of the 60000-node/300000-edge synthetic "
-                      f"shard, fp16 model, {elapsed:.1f} s, oracle/gine_torch.py "
-                      f"(reference aten op sequence), host has {os.cpu_count()} cpus"}
+    cpus = os.cpu_count() or 1
+    counts = sorted({min(c, cpus) for c in (8, 16, 32, 64, cpus)})
+    rates, spent = {}, 0.0
+    for threads in counts:
+        torch.set_num_threads(threads)
+        gine_torch.encode(params, *arrays)                       # warm
+        done, began = 0, time.perf_counter()
+        while done < 2 or time.perf_counter() - began < seconds / len(counts):
+            gine_torch.encode(params, *arrays)
+            done += 1
+        elapsed = time.perf_counter() - began
+        spent += elapsed
+        rates[threads] = done * NODES / elapsed
+    best = max(rates, key=rates.get)
+    listing = ", ".join(f"{t} threads {r / 1e3:.1f} k" for t, r in rates.items())
+    return {"value": rates[best], "unit": "nodes/s", "cores": best, "kind": "port",
+            "sample": f"encodes of the 60000-node/300000-edge synthetic shard, fp16 model, "
+                      f"{spent:.1f} s in all, oracle/gine_torch.py (reference aten op "
+                      f"sequence); nodes/s by torch thread count: {listing}; host has "
+                      f"{cpus} cpus"}
+
+
+def distance_leg(rows: int, device) -> dict:
+    """BASELINE configs[3]: nearest other row of every row, N x N never materialised."""
+    from ginfinity_amd import distance, synthetic
+    points = torch.from_numpy(synthetic.unit_rows(0, rows)).to(device)
+    distance.nearest(points[:4096], points[:4096], metric="l2")          # warm
+    torch.cuda.synchronize(device)
+    began, ended = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    began.record()
+    distance.nearest(points, metric="l2", exclude_self=True)
+    ended.record()
+    torch.cuda.synchronize(device)
+    seconds = began.elapsed_time(ended) * 1e-3
+    tflops = 2.0 * rows * rows * 128 / seconds / 1e12
+    return {"workload": f"all-pairs L2 nearest over {rows} x 128 fp16 unit rows "
+                        "(BASELINE configs[3]); parity unpinned: the reference has no "
+                        "implementation of this step",
+            "seconds": seconds, "pairs_per_s": rows * rows / seconds,
+            "roofline": {"bound": "mfma", "achieved": tflops, "peak": MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS,
+                         "kernel": "k_pairwise"}}
 
 
 def main() -> None:
@@ -175,9 +231,6 @@ def main() -> None:
     lanes = max(1, args.streams)
     encoders = [Ginfinity.load(f"cuda:{local_rank}") for _ in range(lanes)]
     engines = [e._engine for e in encoders]
-    layer_workgroups = args.layer_workgroups or (256 if lanes >= 3 else 512)
-    for e in engines:   # several layer launches in flight: let two of them share every CU
-        e.set_layer_workgroups(0 if layer_workgroups == 512 else layer_workgroups)
     streams = [torch.cuda.Stream(device=device) for _ in range(lanes)]
     engine = engines[0]
 
@@ -232,12 +285,38 @@ def main() -> None:
         elapsed = float(worst.item())
     fence()
 
-    # ---- per-kernel device time (HIP events on the launch stream), rank 0 -------
+    # ---- per-kernel device time (HIP events on the launch streams), rank 0 ------------
     roofline = None
     kernels = None
     if rank == 0:
-        engine.set_layer_workgroups(0)   # the roofline figure is the kernel at its default grid
-        engine.set_timing(2)      # no events between the layer launches that are averaged
+        def layer_roofline(layer_ms: float) -> dict:
+            achieved = LAYER_BYTES / (layer_ms * 1e-3) / 1e9
+            return {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "kernel_ms": layer_ms,
+                    "mfma_tflops": LAYER_FLOPS / (layer_ms * 1e-3) / 1e12,
+                    "mfma_frac": LAYER_FLOPS / (layer_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS}
+
+        def plain_layer_ms(times: list[float]) -> float:
+            # marks: setup | layer 1 .. layer L | stand-alone head (0 for fp16 output, where
+            # the last layer's launch runs the head too); layers 1 .. L-1 carry no head
+            plain = times[1:-2]
+            return sum(plain) / len(plain)
+
+        # (1) the timed configuration: every lane busy, events (none between the plain layer
+        # launches) on each lane's own stream
+        for e in engines:
+            e.set_timing(2)
+        batches, samples = min(max(args.steps // lanes, 1), 16), []
+        for batch in range(batches):
+            for lane in range(lanes):
+                step(batch * lanes + lane)
+            torch.cuda.synchronize(device)
+            samples += [plain_layer_ms(e.kernel_times_ms()) for e in engines]
+        for e in engines:
+            e.set_timing(False)
+        timed_ms = sum(samples) / len(samples)
+
+        # (2) one shard at a time on torch's current stream, with the other kernels' times
+        engine.set_timing(2)
         rounds = min(args.steps, 50)
         sums = None
         csr_ms = 0.0
@@ -254,24 +333,23 @@ def main() -> None:
             sums = times if sums is None else [a + b for a, b in zip(sums, times)]
         engine.set_timing(False)
         mean = [t / rounds for t in sums]
-        # marks: setup | layer 1 .. layer L | (stand-alone head: 0 for fp16 output, where
-        # the last layer's launch runs the head too)
-        plain_layers = mean[1:-2]
-        layer_ms = sum(plain_layers) / len(plain_layers)
-        achieved = LAYER_BYTES / (layer_ms * 1e-3) / 1e9
         roofline = {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "kernel": "k_gine_layer_f16", "algorithmic_bytes_per_launch": LAYER_BYTES,
+            "configuration": f"{lanes} shard(s) in flight on {lanes} stream(s), as timed",
+            **layer_roofline(timed_ms),
             "traffic": measured_traffic("k_gine_layer_f16"),
-            "kernel": "k_gine_layer_f16", "kernel_ms": layer_ms,
-            "algorithmic_bytes_per_launch": LAYER_BYTES,
-            "mfma_tflops": LAYER_FLOPS / (layer_ms * 1e-3) / 1e12,
-            "mfma_frac": LAYER_FLOPS / (layer_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+            "isolated": {"configuration": "one shard at a time", **layer_roofline(plain_layer_ms(mean))},
             "pipeline_frac": PIPELINE_BYTES * world * args.steps / elapsed / 1e9
                              / (HBM_PEAK_GBS * world),
         }
-        kernels = {"csr_build_ms": csr_ms / rounds, "setup_plans_input_linear_ms": mean[0],
-                   "layer_ms": plain_layers, "last_layer_with_head_normalise_ms": mean[-2]}
+        kernels = {"configuration": "one shard at a time", "csr_build_ms": csr_ms / rounds,
+                   "setup_plans_input_linear_ms": mean[0], "layer_ms": mean[1:-2],
+                   "last_layer_with_head_normalise_ms": mean[-2]}
+
+    distance = None
+    if rank == 0 and world == 1 and args.distance_rows > 0:
+        distance = distance_leg(args.distance_rows, device)
 
     baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -291,10 +369,10 @@ def main() -> None:
                                    "fp16 model, fp16 normalised output",
                        "nodes_per_step": NODES, "edges_per_step": EDGES,
                        "shards_per_rank": POOL, "streams_per_gpu": lanes,
-                       "layer_workgroups": layer_workgroups,
                        "rccl_ranks": dist.get_world_size() if distributed else 0,
                        "parallelism": f"shard-parallel x{world}"},
-            "roofline": roofline, "cpu_baseline": baseline, "kernels_ms": kernels,
+            "roofline": roofline, "cpu_baseline": baseline, "distance": distance,
+            "kernels_ms": kernels,
         }))
     if distributed:
         dist.destroy_process_group()

@@ -16,7 +16,7 @@ GFY_OK = 0
 GFY_ERR_INVALID, GFY_ERR_UNSUPPORTED, GFY_ERR_HIP, GFY_ERR_WORKSPACE = 1, 2, 3, 4
 GFY_F16, GFY_F32, GFY_F64 = 0, 1, 2
 GFY_L2, GFY_COSINE = 0, 1
-GFY_OPT_LAYER_KERNEL, GFY_OPT_SEPARATE_HEAD, GFY_OPT_TUNE = 1, 2, 3
+GFY_OPT_SEPARATE_HEAD = 2
 ABI_VERSION = 1
 
 #: every symbol include/gfy.h declares: (restype, argtypes)
@@ -41,7 +41,6 @@ SIGNATURES: dict[str, tuple] = {
                                   c_void_p, c_int64, c_int64, c_int, c_void_p,
                                   c_void_p, c_size_t, c_void_p]),
     "gfy_encoder_set_timing": (c_int, [c_void_p, c_int]),
-    "gfy_encoder_set_layer_workgroups": (c_int, [c_void_p, c_int]),
     "gfy_encoder_set_option": (c_int, [c_void_p, c_int, c_int]),
     "gfy_encoder_get_timing": (c_int, [c_void_p, c_void_p, c_int,
                                        POINTER(c_int)]),

@@ -48,6 +48,7 @@ def build(force: bool = False, verbose: bool = False, stamps: bool = False) -> P
     suffix = ".stamps.o" if stamps else ".o"
     library = CSRC / "libgfy_stamps.so" if stamps else LIBRARY
     extra = ("-DGFY_STAMPS",) if stamps else ()
+    extra += tuple(os.environ.get("GFY_EXTRA_FLAGS", "").split())   # experiments (-DGFY_...)
     jobs = []
     for name in SOURCES:
         source, obj = CSRC / name, CSRC / (Path(name).stem + suffix)

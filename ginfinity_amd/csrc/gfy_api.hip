@@ -40,6 +40,17 @@ void pack_b_fragments(const f16* w, int n_out, int k_in, f16* frag) {
                 8 * (lane >> 5) + j];
 }
 
+void pack_k_chained(const f16* w, int n_out, int k_in, f16* frag) {
+  const int blocks = n_out / 32, ksteps = k_in / 16;
+  for (int blk = 0; blk < blocks; ++blk)
+    for (int s = 0; s < ksteps; ++s)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j)
+          frag[(((size_t)blk * ksteps + s) * 64 + lane) * 8 + j] =
+              w[(size_t)(32 * blk + (lane & 31)) * k_in + 16 * s + 8 * (j >> 2) +
+                4 * (lane >> 5) + (j & 3)];
+}
+
 void pack_chain_fragments(const f16* w, int n_out, int k_in, f16* frag) {
   const int blocks = n_out / 32, ksteps = k_in / 16;
   for (int blk = 0; blk < blocks; ++blk)
@@ -158,7 +169,7 @@ int gfy_encoder_create(const void* weight_pack_host, size_t bytes,
   Blob blob;
   // offsets first (pointers are fixed up after the single upload)
   struct LayerOff {
-    size_t table, w0, b0, alpha, shift, w1, b1, lg, lb, w1c, image;   // f16 mode
+    size_t w01, image;                                                // f16 mode
     size_t ftable, fw0, fb0, falpha, fshift, fw1, fb1, flg, flb;      // f32 mode
     float scale, one_plus_eps;
   };
@@ -171,12 +182,13 @@ int gfy_encoder_create(const void* weight_pack_host, size_t bytes,
   if (model_dtype == GFY_F16) {
     o_win = blob.reserve((size_t)H * 8 * sizeof(f16));
     o_bin = blob.reserve(H * sizeof(f16));
-    for (int c = 0; c < H; ++c) {
-      // packed [c & 7][c >> 3][k]: see k_input_linear_f16
+    for (int p = 0; p < H; ++p) {
+      // stored position p holds channel stored_channel(p); packed [p & 7][p >> 3][k]: see
+      // k_input_linear_f16
+      const int c = stored_channel(p);
       for (int k = 0; k < kInDim; ++k)
-        blob.at<f16>(o_win)[((c & 7) * 16 + (c >> 3)) * 8 + k] =
-            rh(w_in[c * kInDim + k]);
-      blob.at<f16>(o_bin)[c] = rh(b_in[c]);
+        blob.at<f16>(o_win)[((p & 7) * 16 + (p >> 3)) * 8 + k] = rh(w_in[c * kInDim + k]);
+      blob.at<f16>(o_bin)[p] = rh(b_in[c]);
     }
   } else {
     o_win = blob.reserve((size_t)H * kInDim * 4);
@@ -204,78 +216,54 @@ int gfy_encoder_create(const void* weight_pack_host, size_t bytes,
     const float* lb = rd.take(H);
     LayerOff& o = lo[l];
     if (model_dtype == GFY_F16) {
-      o.table = blob.reserve((size_t)kMaxEdgeTypes * H * sizeof(f16));
-      for (int t = 0; t < ED; ++t)
-        for (int c = 0; c < H; ++c)  // R(R(W[c][t]) + R(b[c]))  — one-hot Linear
-          blob.at<f16>(o.table)[t * H + c] =
-              rh((float)rh(ew[c * ED + t]) + (float)rh(eb[c]));
       o.scale = (float)rh(1.0f + (float)rh(eps[0]));  // fp16 scalar (1 + eps)
+      // [W0 | W1] fragments: every B operand of the layer kernel is an MFMA result (or a
+      // stored row, which has the same order) used in place
+      o.w01 = blob.reserve((size_t)2 * M * H * sizeof(f16));
       tmp.resize((size_t)M * H);
       for (size_t i = 0; i < tmp.size(); ++i) tmp[i] = rh(w0[i]);
-      o.w0 = blob.reserve(tmp.size() * sizeof(f16));
-      pack_b_fragments(tmp.data(), M, H, blob.at<f16>(o.w0));
+      pack_k_chained(tmp.data(), M, H, blob.at<f16>(o.w01));
       for (size_t i = 0; i < tmp.size(); ++i) tmp[i] = rh(w1[i]);
-      o.w1 = blob.reserve(tmp.size() * sizeof(f16));
-      pack_b_fragments(tmp.data(), H, M, blob.at<f16>(o.w1));
-      o.w1c = blob.reserve(2 * tmp.size() * sizeof(f16));   // [W0 fragments | W1 chained]
-      std::memcpy(blob.at<f16>(o.w1c), blob.at<f16>(o.w0), tmp.size() * sizeof(f16));
-      pack_chain_fragments(tmp.data(), H, M, blob.at<f16>(o.w1c) + tmp.size());
-      o.b0 = blob.reserve(M * sizeof(f16));
-      o.alpha = blob.reserve(M * 4);
-      o.shift = blob.reserve(M * 4);
-      for (int c = 0; c < M; ++c) {
-        blob.at<f16>(o.b0)[c] = rh(b0[c]);
-        const float g = (float)rh(bg[c]), b = (float)rh(bb[c]);
-        const float mean = (float)rh(bm[c]), var = (float)rh(bv[c]);
-        const float invstd = 1.0f / std::sqrt(var + 1e-5f);
-        const float alpha = invstd * g;
-        const float prod = mean * alpha;  // separate rounding (no fma)
-        blob.at<float>(o.alpha)[c] = alpha;
-        blob.at<float>(o.shift)[c] = b - prod;
-      }
-      o.b1 = blob.reserve(H * sizeof(f16));
-      o.lg = blob.reserve(H * sizeof(f16));
-      o.lb = blob.reserve(H * sizeof(f16));
-      for (int c = 0; c < H; ++c) {
-        blob.at<f16>(o.b1)[c] = rh(b1[c]);
-        blob.at<f16>(o.lg)[c] = rh(lg[c]);
-        blob.at<f16>(o.lb)[c] = rh(lb[c]);
-      }
-      // LDS image of gine_layer3.inc, in the order its lanes read it: edge table, the
-      // -inf row of idle slots, alpha / shift / b0 as [block][lane half][register] of the
-      // 32x32 MFMA result, b1 / gamma / beta as [lane half][chunk][element] of the hidden
-      // state's register layout
+      pack_k_chained(tmp.data(), H, M, blob.at<f16>(o.w01) + (size_t)M * H);
+      // LDS image of gine_layer.inc, in the order its lanes read it
       o.image = blob.reserve(7680);
-      {
-        char* im = blob.at<char>(o.image);
-        std::memcpy(im, blob.at<char>(o.table), (size_t)kMaxEdgeTypes * H * sizeof(f16));
-        f16* ninf = reinterpret_cast<f16*>(im + 4096);
-        for (int c = 0; c < H; ++c) ninf[c] = (f16)(-INFINITY);
-        float* ia = reinterpret_cast<float*>(im + 4352);
-        float* is = reinterpret_cast<float*>(im + 4352 + 1024);
-        f16* ib0 = reinterpret_cast<f16*>(im + 4352 + 2048);
-        for (int b = 0; b < M / 32; ++b)
-          for (int half = 0; half < 2; ++half)
-            for (int reg = 0; reg < 16; ++reg) {
-              const int c = gemm_result_channel(b, half, reg);
-              const int at = (b * 2 + half) * 16 + reg;
-              ia[at] = blob.at<float>(o.alpha)[c];
-              is[at] = blob.at<float>(o.shift)[c];
-              ib0[at] = blob.at<f16>(o.b0)[c];
-            }
-        f16* ib1 = reinterpret_cast<f16*>(im + 4352 + 2048 + 512);
-        f16* ig = ib1 + H;
-        f16* ib = ig + H;
+      char* im = blob.at<char>(o.image);
+      f16* table = reinterpret_cast<f16*>(im);           // [17][128], stored order
+      for (int t = 0; t < ED; ++t)
+        for (int p = 0; p < H; ++p) {   // R(R(W[c][t]) + R(b[c]))  — one-hot Linear
+          const int c = stored_channel(p);
+          table[t * H + p] = rh((float)rh(ew[c * ED + t]) + (float)rh(eb[c]));
+        }
+      for (int p = 0; p < H; ++p) table[kMaxEdgeTypes * H + p] = (f16)(-INFINITY);
+      float* ia = reinterpret_cast<float*>(im + 4352);
+      float* is = reinterpret_cast<float*>(im + 4352 + 1024);
+      f16* ib0 = reinterpret_cast<f16*>(im + 4352 + 2048);
+      for (int blk = 0; blk < M / 32; ++blk)
         for (int half = 0; half < 2; ++half)
-          for (int ks = 0; ks < 8; ++ks)
-            for (int j = 0; j < 8; ++j) {
-              const int c = hidden_layout_channel(half, ks, j);
-              const int at = (half * 8 + ks) * 8 + j;
-              ib1[at] = blob.at<f16>(o.b1)[c];
-              ig[at] = blob.at<f16>(o.lg)[c];
-              ib[at] = blob.at<f16>(o.lb)[c];
-            }
-      }
+          for (int reg = 0; reg < 16; ++reg) {
+            const int c = gemm_result_channel(blk, half, reg);
+            const int at = (blk * 2 + half) * 16 + reg;
+            const float g = (float)rh(bg[c]), b = (float)rh(bb[c]);
+            const float mean = (float)rh(bm[c]), var = (float)rh(bv[c]);
+            const float invstd = 1.0f / std::sqrt(var + 1e-5f);
+            const float alpha = invstd * g;
+            const float prod = mean * alpha;  // separate rounding (no fma)
+            ia[at] = alpha;
+            is[at] = b - prod;
+            ib0[at] = rh(b0[c]);
+          }
+      f16* ib1 = reinterpret_cast<f16*>(im + 4352 + 2048 + 512);
+      f16* ig = ib1 + H;
+      f16* ib = ig + H;
+      for (int blk = 0; blk < H / 32; ++blk)
+        for (int half = 0; half < 2; ++half)
+          for (int reg = 0; reg < 16; ++reg) {
+            const int c = gemm_result_channel(blk, half, reg);
+            const int at = (blk * 2 + half) * 16 + reg;
+            ib1[at] = rh(b1[c]);
+            ig[at] = rh(lg[c]);
+            ib[at] = rh(lb[c]);
+          }
     } else {
       auto put = [&](const float* src, size_t n) {
         const size_t off = blob.reserve(n * 4);
@@ -316,33 +304,33 @@ int gfy_encoder_create(const void* weight_pack_host, size_t bytes,
   const float* wb = rd.take((size_t)kOutDim * H);
   const float* bbias = rd.take(kOutDim);
   if (model_dtype == GFY_F16) {
+    // stand-alone head kernel: reads stored rows (k chained), writes natural rows
     tmp.resize((size_t)H * H);
     for (size_t i = 0; i < tmp.size(); ++i) tmp[i] = rh(wa[i]);
     o_wa = blob.reserve(tmp.size() * sizeof(f16));
-    pack_b_fragments(tmp.data(), H, H, blob.at<f16>(o_wa));
+    pack_k_chained(tmp.data(), H, H, blob.at<f16>(o_wa));
+    // fused head: head.0 k-chained, head.2 chained with its rows dealt into natural chunks
+    o_hchain = blob.reserve((size_t)2 * H * H * sizeof(f16));
+    std::memcpy(blob.at<f16>(o_hchain), blob.at<f16>(o_wa), (size_t)H * H * sizeof(f16));
     for (size_t i = 0; i < tmp.size(); ++i) tmp[i] = rh(wb[i]);
     o_wb = blob.reserve(tmp.size() * sizeof(f16));
     pack_b_fragments(tmp.data(), kOutDim, H, blob.at<f16>(o_wb));
+    pack_chain_fragments(tmp.data(), kOutDim, H, blob.at<f16>(o_hchain) + (size_t)H * H);
     o_ba = blob.reserve(H * sizeof(f16));
     o_bb = blob.reserve(kOutDim * sizeof(f16));
     for (int c = 0; c < H; ++c) {
       blob.at<f16>(o_ba)[c] = rh(ba[c]);
       blob.at<f16>(o_bb)[c] = rh(bbias[c]);
     }
-    // gine_layer3.inc: head.0 as plain fragments, head.2 chained behind it; biases in the
-    // orders the two results come out in
-    o_hchain = blob.reserve((size_t)2 * H * H * sizeof(f16));
-    std::memcpy(blob.at<f16>(o_hchain), blob.at<f16>(o_wa), (size_t)H * H * sizeof(f16));
-    pack_chain_fragments(tmp.data(), kOutDim, H, blob.at<f16>(o_hchain) + (size_t)H * H);
     o_himage = blob.reserve(512);
     {
       f16* iba = blob.at<f16>(o_himage);
       f16* ibb = iba + H;
-      for (int b = 0; b < H / 32; ++b)
+      for (int blk = 0; blk < H / 32; ++blk)
         for (int half = 0; half < 2; ++half)
           for (int reg = 0; reg < 16; ++reg)
-            iba[(b * 2 + half) * 16 + reg] =
-                blob.at<f16>(o_ba)[gemm_result_channel(b, half, reg)];
+            iba[(blk * 2 + half) * 16 + reg] =
+                blob.at<f16>(o_ba)[gemm_result_channel(blk, half, reg)];
       for (int half = 0; half < 2; ++half)
         for (int ks = 0; ks < 8; ++ks)
           for (int j = 0; j < 8; ++j)
@@ -384,18 +372,9 @@ int gfy_encoder_create(const void* weight_pack_host, size_t bytes,
     for (int l = 0; l < L; ++l) {
       LayerF16& d = enc->f16.layer[l];
       const LayerOff& o = lo[l];
-      d.edge_table = H16(o.table);
       d.scale = o.scale;
-      d.w0_frag = H16(o.w0);
-      d.b0 = H16(o.b0);
-      d.bn_alpha = F32p(o.alpha);
-      d.bn_shift = F32p(o.shift);
-      d.w1_frag = H16(o.w1);
-      d.b1 = H16(o.b1);
-      d.ln_gamma = H16(o.lg);
-      d.ln_beta = H16(o.lb);
-      d.w01_image = H16(o.w1c);
-      d.image3 = base + o.image;
+      d.w01_image = H16(o.w01);
+      d.image = base + o.image;
     }
     enc->f16.head = HeadF16{H16(o_wa), H16(o_ba), H16(o_wb), H16(o_bb), H16(o_hchain),
                             base + o_himage};
@@ -437,32 +416,14 @@ int gfy_encoder_set_timing(gfy_encoder* enc, int enable) {
   return GFY_OK;
 }
 
-int gfy_encoder_set_layer_workgroups(gfy_encoder* enc, int workgroups) {
-  clear_error();
-  GFY_REQUIRE(enc != nullptr, GFY_ERR_INVALID,
-              "gfy_encoder_set_layer_workgroups: encoder is NULL");
-  GFY_REQUIRE(workgroups >= 0 && workgroups <= 65536, GFY_ERR_INVALID,
-              "gfy_encoder_set_layer_workgroups: %d outside 0..65536", workgroups);
-  enc->layer_workgroups = workgroups;
-  return GFY_OK;
-}
-
 int gfy_encoder_set_option(gfy_encoder* enc, int option, int value) {
   clear_error();
   GFY_REQUIRE(enc != nullptr, GFY_ERR_INVALID, "gfy_encoder_set_option: encoder is NULL");
   switch (option) {
-    case GFY_OPT_LAYER_KERNEL:
-      GFY_REQUIRE(value == 2 || value == 3, GFY_ERR_INVALID,
-                  "gfy_encoder_set_option: GFY_OPT_LAYER_KERNEL must be 2 or 3 (got %d)", value);
-      enc->layer_kernel = value;
-      return GFY_OK;
     case GFY_OPT_SEPARATE_HEAD:
       GFY_REQUIRE(value == 0 || value == 1, GFY_ERR_INVALID,
                   "gfy_encoder_set_option: GFY_OPT_SEPARATE_HEAD must be 0 or 1 (got %d)", value);
       enc->separate_head = value;
-      return GFY_OK;
-    case GFY_OPT_TUNE:
-      enc->tune = value;
       return GFY_OK;
     default:
       set_error("gfy_encoder_set_option: unknown option %d", option);

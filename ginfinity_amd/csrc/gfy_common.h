@@ -73,37 +73,38 @@ class PerDeviceOnce {
   unsigned long long done_[4] = {};
 };
 
-// ---- fp16 layer parameters on the device (see gine_f16.hip for the layouts) ------
+// ---- fp16 layer parameters on the device (layouts: gine_layer.inc, gfy_api.hip) ---------
+// Hidden rows are stored with the channel groups 4-7 and 8-11 of every 16 swapped: 16-byte
+// chunk 2 s + hq of a row is then the eight values lane half hq holds for k-step s in the
+// MFMA C/D layout, so activations move between memory, LDS and MFMA operands as whole chunks.
+inline int stored_channel(int position) {   // an involution: bits 2 and 3 trade places
+  return (position & ~12) | ((position & 4) << 1) | ((position & 8) >> 1);
+}
+inline int gemm_result_channel(int block, int half, int reg) {   // 32x32 C/D layout
+  return 32 * block + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+}
+
 struct LayerF16 {
-  const f16* edge_table;  // [kMaxEdgeTypes][128]  R(W_edge[:,t] + b_edge), rows >= edge_dim zero
   float scale;            // fp16 value R(1 + R(eps)) widened to fp32
-  const f16* w0_frag;     // mlp.0.weight in MFMA B-fragment order
-  const f16* b0;          // [256]
-  const float* bn_alpha;  // [256]  invstd * gamma          (fp32, from fp16-rounded buffers)
-  const float* bn_shift;  // [256]  beta - mean * alpha
-  const f16* w1_frag;     // mlp.4.weight in MFMA B-fragment order
-  const f16* b1;          // [128]
-  const f16* ln_gamma;    // [128]
-  const f16* ln_beta;     // [128]
-  // third-generation layer kernel (gine_layer3.inc)
-  const f16* w01_image;   // 128 KB: mlp.0.weight fragments | mlp.4.weight fragments for a B
-                          // operand taken from the first product's result (pack_chain_fragments)
-  const void* image3;     // 7,680-byte LDS image: edge table + -inf row, alpha, shift, b0,
-                          // b1, gamma, beta in the orders the lanes read them
+  const f16* w01_image;   // 128 KB: mlp.0.weight | mlp.4.weight fragments (pack_k_chained)
+  const void* image;      // 7,680-byte LDS image: edge table R(W_edge[:,t] + b_edge) in stored
+                          // order + the -inf row of idle slots; BatchNorm alpha = invstd*gamma,
+                          // shift = beta - mean*alpha (fp32, from fp16-rounded buffers), b0, b1,
+                          // LayerNorm gamma, beta as [block][lane half][register] of an MFMA result
 };
 
 struct HeadF16 {
-  const f16* wa_frag;  // head.0.weight fragments
+  const f16* wa_frag;  // head.0.weight fragments, pack_k_chained (the stand-alone head kernel)
   const f16* ba;       // [128]
-  const f16* wb_frag;  // head.2.weight fragments
+  const f16* wb_frag;  // head.2.weight fragments, pack_b_fragments
   const f16* bb;       // [128]
-  const f16* w_chain;  // gine_layer3.inc: head.0 fragments (32 KB) | head.2 chained (32 KB)
-  const void* image3;  // 512-byte LDS image: ba (GEMM result order) | bb (hidden order)
+  const f16* w_image;  // 64 KB: head.0 (pack_k_chained) | head.2 (pack_chain_fragments)
+  const void* image;   // 512 B: ba as [block][half][register] | bb as natural 16-byte chunks
 };
 
 struct ModelF16 {
-  const f16* w_in;  // [8][16][8]: [c & 7][c >> 3][k], k padded 7 -> 8 with zero
-  const f16* b_in;  // [128]
+  const f16* w_in;  // [8][16][8]: [p & 7][p >> 3][k] for stored position p, k padded 7 -> 8
+  const f16* b_in;  // [128] in stored order
   LayerF16 layer[kMaxLayers];
   HeadF16 head;
 };
@@ -145,10 +146,7 @@ struct gfy_encoder {
   // after the stand-alone head.  Mode 2 leaves out the events between layer launches
   // 1 .. layers-1: an event between two dependent kernels costs ~2.5 us of stream time that
   // rocprof's kernel durations do not contain.
-  int layer_workgroups = 0;   // gfy_encoder_set_layer_workgroups (0 = default)
-  int layer_kernel = 3;       // GFY_OPT_LAYER_KERNEL: 3 = gine_layer3.inc, 2 = gine_layer.inc
   int separate_head = 0;      // GFY_OPT_SEPARATE_HEAD
-  int tune = 0;               // GFY_OPT_TUNE: diagnostic schedule switches of gine_layer3.inc
   int timing = 0;
   hipEvent_t events[gfy::kMaxLayers + 3] = {};
   mutable int events_recorded = 0;
@@ -231,20 +229,16 @@ __device__ __forceinline__ void dma_wait_all() {
   asm volatile("" ::: "memory");
 }
 
-// W[n_out][k_in] (row-major fp16) -> MFMA 32x32x16 B-operand fragment order:
-// frag[(ntile * ksteps + ks) * 64 + lane][8] = W[32*ntile + (lane & 31)][16*ks + 8*(lane >> 5) + j]
+// W[n_out][k_in] (row-major fp16) -> fragments of the MFMA 32x32x16 A operand (out^T = W . in^T):
+// frag[(block * ksteps + s) * 64 + lane][j] = W[row(block, lane & 31)][k(s, lane >> 5, j)]
+//   pack_b_fragments      natural:  row = 32 block + m,  k = 16 s + 8 half + j
+//   pack_k_chained        the B operand is an MFMA result used in place (gine_layer.inc):
+//                         k = 16 s + 8 (j >> 2) + 4 half + (j & 3), rows natural
+//   pack_chain_fragments  same k; rows dealt so that the result's registers are natural
+//                         16-byte chunks of the output row (head.2 -> embedding)
 void pack_b_fragments(const f16* w, int n_out, int k_in, f16* frag);
-
-// Fragments of the SECOND product of a chain (gine_layer3.inc): its B operand is the first
-// product's 32x32 result converted in place, so k-step s holds, in element j of lane half h,
-// input channel 16 s + 8 (j >> 2) + 4 h + (j & 3); and its rows are dealt so that the result
-// lands in the hidden-state layout (lane half h, register i of block blk = output channel
-// 32 blk + 16 (i >> 3) + 8 h + (i & 7)).
+void pack_k_chained(const f16* w, int n_out, int k_in, f16* frag);
 void pack_chain_fragments(const f16* w, int n_out, int k_in, f16* frag);
-// index helpers shared by the constant images
-inline int gemm_result_channel(int block, int half, int reg) {   // 32x32 C/D layout
-  return 32 * block + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-}
 inline int hidden_layout_channel(int half, int ks, int j) { return 16 * ks + 8 * half + j; }
 
 }  // namespace gfy

@@ -6,8 +6,8 @@
 //   _model.py:41-46   message / aggregate / (1+eps)x / MLP |
 //   _model.py:34-36   Linear-BatchNorm-ReLU-Linear         |-> k_gine_layer_f16  (gine_layer.inc)
 //   _model.py:69-71   LayerNorm + residual                 |
-//   _model.py:72      head Linear-ReLU-Linear              |-> second pass of the last layer's
-//   api.py:250-259    fp64 normalise, core rows, dtype     |   launch (fp16 out) / k_head_f16
+//   _model.py:72      head Linear-ReLU-Linear              |-> tail of the last layer's launch
+//   api.py:250-259    fp64 normalise, core rows, dtype     |   (fp16 out) / k_head_f16
 //
 // Numerics contract (oracle/gine_numpy.py): every reference op
 // boundary rounds to fp16 in-register; arithmetic inside an op is fp32
@@ -15,18 +15,11 @@
 // "fp32 op then round" and the native fp16 op agree exactly (sum/product of two
 // fp16 values: 24 >= 2*11+2 bits).
 //
-// One tile of the layer kernel goes through four phases behind workgroup barriers:
-//   A  gather-sum   16 lanes x 16 B per node row, in-edges in CSR (= COO) order out of
-//                   LDS, fp32 accumulate, z -> LDS (fp16, XOR-swizzled 16-B chunks)
-//   B  GEMM1        U^T = W0 . Z^T on v_mfma_f32_32x32x16_f16, W0 fragments live in
-//                   registers for the whole launch; epilogue bias, round, BatchNorm fma,
-//                   round, ReLU -> LDS
-//   C  GEMM2        W^T = W1 . V^T, W1 fragments in registers; bias, round -> LDS
-//   D  LayerNorm    fp32 two-pass moments over 16 lanes (DPP), fma-fma affine, round,
-//                   residual add, 16-B coalesced store of the new hidden row
-// The node index sits on the MFMA lane (C^T form), so each lane's 4 consecutive
-// accumulator registers are 4 consecutive channels of one node: 8-byte LDS
-// writes, no transposition.  Schedule, LDS-DMA look-ahead and tile plans: gine_layer.inc.
+// One wave owns one 32-node tile from the gather to the store (gine_layer.inc): gather-sum out
+// of LDS with the accumulation on the matrix cores, both MLP products with the weights read
+// from LDS and the activations in registers, BatchNorm / LayerNorm / residual in place.
+// Hidden rows are kept in memory in the order the MFMA lanes hold them (gfy_common.h
+// stored_channel); k_copy_rows_f16 restores the natural order for the parity taps.
 #include <cstdlib>
 
 #include "gfy_common.h"
@@ -377,17 +370,23 @@ __global__ __launch_bounds__(kThreads, 2) void k_head_f16(
   }
 }
 
+// hidden rows in stored order -> natural channel order (parity taps): per 16 channels the
+// groups 4-7 and 8-11 trade places, i.e. the inner 8-byte halves of two 16-byte chunks
 __global__ __launch_bounds__(256) void k_copy_rows_f16(const f16* __restrict__ src,
                                                        f16* __restrict__ dst,
-                                                       int64_t chunks) {
+                                                       int64_t groups /* of 16 channels */) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < chunks; i += stride)
-    reinterpret_cast<f16x8*>(dst)[i] = reinterpret_cast<const f16x8*>(src)[i];
+  for (; i < groups; i += stride) {
+    const u32x4 a = reinterpret_cast<const u32x4*>(src)[2 * i];
+    const u32x4 b = reinterpret_cast<const u32x4*>(src)[2 * i + 1];
+    const u32x4 lo = {a[0], a[1], b[0], b[1]}, hi = {a[2], a[3], b[2], b[3]};
+    reinterpret_cast<u32x4*>(dst)[2 * i] = lo;
+    reinterpret_cast<u32x4*>(dst)[2 * i + 1] = hi;
+  }
 }
 
 #include "gine_layer.inc"
-#include "gine_layer3.inc"
 
 int persistent_grid(int num_tiles) {
   int g = num_tiles < 256 ? num_tiles : 256;
@@ -419,10 +418,12 @@ extern "C" int gfy_debug_stamps(unsigned long long* host /*[256][16]*/, int rese
 static size_t h_buffer_bytes(int64_t n) {
   return align_up((size_t)(n + 2 * kTile) * kHidden * sizeof(f16), 256);
 }
-// ... plus one plan per 32-node tile (gine_layer3.inc; gine_layer.inc's are larger)
+// ... plus one plan per 32-node tile (gine_layer.inc)
 static size_t plan_bytes(int64_t n) {
-  static_assert(kPlanBytes >= kP3Bytes && kT2 == kT3, "one plan area serves both generations");
-  return align_up((size_t)((n + kT2 - 1) / kT2) * kPlanBytes, 256);
+  return align_up((size_t)((n + kLTile - 1) / kLTile) * kPlanBytes, 256);
+}
+size_t encode_f16_workspace_bytes(int64_t n, int64_t /*e*/) {
+  return 2 * h_buffer_bytes(n) + plan_bytes(n);
 }
 
 // > 64 KB of dynamic LDS needs an opt-in per kernel and per DEVICE (a process may drive
@@ -430,23 +431,16 @@ static size_t plan_bytes(int64_t n) {
 static PerDeviceOnce g_layer_lds_opt_in;
 static int opt_in_layer_lds() {
   return g_layer_lds_opt_in.run([]() -> int {
-#define GFY_OPT_IN(kernel, bytes)                                                          \
+#define GFY_OPT_IN(kernel)                                                                 \
   GFY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel),                \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes))
-    GFY_OPT_IN((k_gine_layer_f16<true, false>), k2Bytes);
-    GFY_OPT_IN((k_gine_layer_f16<false, false>), k2Bytes);
-    GFY_OPT_IN((k_gine_layer_f16<true, true>), k2Bytes);
-    GFY_OPT_IN((k_gine_layer_f16<false, true>), k2Bytes);
-    GFY_OPT_IN((k_gine_layer3_f16<true, false>), k3Bytes);
-    GFY_OPT_IN((k_gine_layer3_f16<false, false>), k3Bytes);
-    GFY_OPT_IN((k_gine_layer3_f16<true, true>), k3Bytes);
-    GFY_OPT_IN((k_gine_layer3_f16<false, true>), k3Bytes);
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes))
+    GFY_OPT_IN((k_gine_layer_f16<true, false>));
+    GFY_OPT_IN((k_gine_layer_f16<false, false>));
+    GFY_OPT_IN((k_gine_layer_f16<true, true>));
+    GFY_OPT_IN((k_gine_layer_f16<false, true>));
 #undef GFY_OPT_IN
     return GFY_OK;
   });
-}
-size_t encode_f16_workspace_bytes(int64_t n, int64_t /*e*/) {
-  return 2 * h_buffer_bytes(n) + plan_bytes(n);
 }
 
 int launch_encode_f16(const gfy_encoder* enc, const float* x,
@@ -467,17 +461,9 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
   char* plans = (char*)ws + 2 * h_buffer_bytes(n);
   const int num_tiles = (int)((n + kTile - 1) / kTile);   // stand-alone head kernel
   const int grid = persistent_grid(num_tiles);
-  const int layer_tiles = (int)((n + kT2 - 1) / kT2);
-  const bool third = enc->layer_kernel != 2;
-  int layer_grid;
-  if (third) {
-    // one tile per wave, eight per workgroup, XCD x = workgroups x, x + 8, ... (gine_layer3.inc)
-    layer_grid = 8 * ((layer_tiles + 8 * kWaves3 - 1) / (8 * kWaves3));
-  } else {
-    const int layer_cap = enc->layer_workgroups > 0 ? enc->layer_workgroups : 512;   // two per CU
-    layer_grid = layer_tiles < layer_cap ? layer_tiles : layer_cap;
-    layer_grid = (layer_grid + 7) & ~7;                      // whole XCD rounds
-  }
+  const int layer_tiles = (int)((n + kLTile - 1) / kLTile);
+  // one tile per wave, eight per workgroup, XCD x = workgroups x, x + 8, ... (gine_layer.inc)
+  const int layer_grid = 8 * ((layer_tiles + 8 * kLWaves - 1) / (8 * kLWaves));
 
   const int64_t items = n * 16;
   enc->mark(s, 0);
@@ -487,10 +473,7 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
     if (tap_stage == 0)
       k_input_linear_f16<<<linear_blocks, 256, 0, s>>>(x, enc->f16.w_in, enc->f16.b_in, ha,
                                                        (int)n);
-    else if (third)   // + tile plans, once for all layers, in the same launch
-      k_encode_setup3<<<layer_tiles + linear_blocks, 256, 0, s>>>(
-          x, enc->f16.w_in, enc->f16.b_in, ha, (int)n, row_ptr, col, typ, plans, layer_tiles);
-    else
+    else   // + tile plans, once for all layers, in the same launch
       k_encode_setup<<<layer_tiles + linear_blocks, 256, 0, s>>>(
           x, enc->f16.w_in, enc->f16.b_in, ha, (int)n, row_ptr, col, typ, plans, layer_tiles);
   }
@@ -499,21 +482,14 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
   if (const int rc = opt_in_layer_lds()) return rc;
   // fp16 output of a full encode: the last layer's launch runs the head as well
   // (GFY_OPT_SEPARATE_HEAD keeps the stand-alone head kernel: A/B runs and parity tests)
-  const bool fuse_head = tap_stage < 0 && out_dtype == GFY_F16 && stop > 0 &&
-                         (third || n >= kT2) && !enc->separate_head;
+  const bool fuse_head =
+      tap_stage < 0 && out_dtype == GFY_F16 && stop > 0 && !enc->separate_head;
   for (int l = 0; l < stop; ++l) {
     const bool with_head = fuse_head && l == stop - 1;
 #define GFY_LAUNCH_LAYER(RES, HEAD)                                                          \
-  do {                                                                                       \
-    if (third)                                                                               \
-      k_gine_layer3_f16<RES, HEAD><<<layer_grid, kThreads3, k3Bytes, s>>>(                   \
-          enc->f16.layer[l], ha, hb, row_ptr, col, typ, plans, (int)n, layer_tiles,          \
-          enc->f16.head, out_rows, (f16*)out, normalise, enc->tune);                         \
-    else                                                                                     \
-      k_gine_layer_f16<RES, HEAD><<<layer_grid, kThreads2, k2Bytes, s>>>(                    \
-          enc->f16.layer[l], ha, hb, row_ptr, col, typ, plans, (int)n, layer_tiles,          \
-          enc->f16.head, out_rows, (f16*)out, normalise);                                    \
-  } while (0)
+  k_gine_layer_f16<RES, HEAD><<<layer_grid, kLThreads, kLdsBytes, s>>>(                      \
+      enc->f16.layer[l], ha, hb, row_ptr, col, typ, plans, (int)n, layer_tiles, enc->f16.head, \
+      out_rows, (f16*)out, normalise)
     if (enc->residual && with_head) GFY_LAUNCH_LAYER(true, true);
     else if (enc->residual) GFY_LAUNCH_LAYER(true, false);
     else if (with_head) GFY_LAUNCH_LAYER(false, true);
@@ -525,9 +501,9 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
     enc->mark(s, 2 + l);
   }
   if (tap_stage >= 0) {
-    const int64_t chunks = n * 16;
-    int g = (int)((chunks + 255) / 256);
-    k_copy_rows_f16<<<g > 2048 ? 2048 : g, 256, 0, s>>>(ha, (f16*)out, chunks);
+    const int64_t groups = n * 8;
+    int g = (int)((groups + 255) / 256);
+    k_copy_rows_f16<<<g > 2048 ? 2048 : g, 256, 0, s>>>(ha, (f16*)out, groups);
     GFY_CHECK_HIP(hipGetLastError());
     return GFY_OK;
   }

@@ -240,15 +240,9 @@ class DeviceEncoder:
         return out
 
     # -- diagnostics -------------------------------------------------------------------
-    def set_layer_workgroups(self, workgroups: int) -> None:
-        """Cap the layer kernel's grid (0 = default 512).  256 gives more nodes/s when
-        several encodes are in flight on different streams (include/gfy.h)."""
-        native.check(self._lib.gfy_encoder_set_layer_workgroups(
-            self._handle, int(workgroups)), "gfy_encoder_set_layer_workgroups")
-
     def set_option(self, option: int, value: int) -> None:
-        """Diagnostic switches of include/gfy.h (``native.GFY_OPT_*``): which generation
-        of the layer kernel runs, head fused into the last layer launch or not."""
+        """Diagnostic switches of include/gfy.h (``native.GFY_OPT_*``): head fused into the
+        last layer launch or not."""
         native.check(self._lib.gfy_encoder_set_option(
             self._handle, int(option), int(value)), "gfy_encoder_set_option")
 

@@ -166,29 +166,14 @@ int gfy_encode_hidden(gfy_encoder* encoder, const float* node_features,
  * last layer's launch runs the head too and this entry is ~0);
  * *count receives layers+2. */
 int gfy_encoder_set_timing(gfy_encoder* encoder, int enable);
-
-/* Throughput tuning (no reference counterpart).  The fused layer kernel is launched with
- * at most `workgroups` 256-thread workgroups (0 = default: 512, two per CU, the fastest
- * for one encode at a time).  A caller that keeps several encodes in flight on different
- * streams — each on its own hardware queue, see GPU_MAX_HW_QUEUES in bench.py — gets ~5 %
- * more nodes/s with 256: two layer launches then share every CU instead of taking turns,
- * and the prologue of one runs under the tiles of the other (bench.py, 4 streams: 645 ->
- * 678 M nodes/s; one encode at a time loses: 146 -> 183 us).  Rounded up to a multiple
- * of 8; results do not depend on it. */
-int gfy_encoder_set_layer_workgroups(gfy_encoder* encoder, int workgroups);
+int gfy_encoder_get_timing(gfy_encoder* encoder, float* ms_host, int capacity,
+                           int* count);
 
 /* Diagnostic options of one encoder (no reference counterpart; results within the stated
  * tolerances for every setting).  Set between encodes, never read from the environment.
- *   GFY_OPT_LAYER_KERNEL   3 (default): one wave per 32-node tile, weights in LDS, activations
- *                          in registers (csrc/gine_layer3.inc); 2: the previous generation
- *                          (csrc/gine_layer.inc), kept for A/B measurements
- *   GFY_OPT_SEPARATE_HEAD  1: head + normalise as its own launch even for fp16 output
- *   GFY_OPT_TUNE           bit mask of schedule experiments inside the layer kernel (0 =
- *                          the shipped schedule); never changes a result                    */
-enum gfy_option { GFY_OPT_LAYER_KERNEL = 1, GFY_OPT_SEPARATE_HEAD = 2, GFY_OPT_TUNE = 3 };
+ *   GFY_OPT_SEPARATE_HEAD  1: head + normalise as its own launch even for fp16 output      */
+enum gfy_option { GFY_OPT_SEPARATE_HEAD = 2 };
 int gfy_encoder_set_option(gfy_encoder* encoder, int option, int value);
-int gfy_encoder_get_timing(gfy_encoder* encoder, float* ms_host, int capacity,
-                           int* count);
 
 /* ---- all-pairs distance over 128-d embeddings ----------------------------------
  * No reference symbol (the aligner lives in the external `ginfinity-sw`;

@@ -27,7 +27,7 @@ def _run(*flags: str) -> dict:
 
 
 def test_bench_line_contract():
-    line = _run("--steps", "40", "--warmup", "8", "--cpu-seconds", "1")
+    line = _run("--steps", "40", "--warmup", "8", "--cpu-seconds", "2", "--distance-rows", "65536")
     assert line["metric"] == "encoded nodes/sec on 60k-node/300k-edge shards"
     assert line["unit"] == "nodes/s" and line["higher_is_better"] is True
     assert (line["n_gpus"], line["steps"], line["warmup"]) == (1, 40, 8)
@@ -40,21 +40,27 @@ def test_bench_line_contract():
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     assert 0.02 < roof["frac"] < 1.0
-    assert roof["traffic"] is None or roof["traffic"] >= roof["algorithmic_bytes_per_launch"]
+    assert roof["traffic"] is None or roof["traffic"] >= 0.9 * roof["algorithmic_bytes_per_launch"]
+    assert "as timed" in roof["configuration"] and roof["kernel_ms"] > 0
+    assert 0.02 < roof["isolated"]["frac"] < 1.0 and roof["isolated"]["kernel_ms"] > 0
+    dist = line["distance"]
+    assert dist["roofline"]["bound"] == "mfma" and 0.0 < dist["roofline"]["frac"] < 1.0
     cpu = line["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["unit"] == "nodes/s"
     assert cpu["cores"] >= 1 and 0 < cpu["value"] < line["value"] and cpu["sample"]
 
 
 def test_bench_line_one_stream_without_cpu_baseline():
-    line = _run("--steps", "20", "--warmup", "4", "--streams", "1", "--no-cpu-baseline")
-    assert line["cpu_baseline"] is None and line["steps"] == 20
-    assert line["config"]["layer_workgroups"] == 512
+    line = _run("--steps", "20", "--warmup", "4", "--streams", "1", "--no-cpu-baseline",
+                "--distance-rows", "0")
+    assert line["cpu_baseline"] is None and line["steps"] == 20 and line["distance"] is None
+    assert line["config"]["streams_per_gpu"] == 1
 
 
 def test_bench_through_the_rank_launcher_world_size_one():
     """`--spawn` = what `--gpus N>1` does: the parent starts torch.distributed.run, the one
     rank creates the RCCL group, rank 0's line is relayed."""
-    line = _run("--gpus", "1", "--spawn", "--steps", "20", "--warmup", "4", "--no-cpu-baseline")
+    line = _run("--gpus", "1", "--spawn", "--steps", "20", "--warmup", "4", "--no-cpu-baseline",
+                "--distance-rows", "0")
     assert line["n_gpus"] == 1 and line["config"]["rccl_ranks"] == 1
     assert line["value"] > 1e8 and line["cpu_baseline"] is None

@@ -46,8 +46,6 @@ int main(int argc, char** argv) {
   }
   gfy_encoder* enc = nullptr;
   GK(gfy_encoder_create(pack.data(), bytes, GFY_F16, 0, &enc));
-  if (getenv("GFY_BENCH_TUNE")) GK(gfy_encoder_set_option(enc, GFY_OPT_TUNE, atoi(getenv("GFY_BENCH_TUNE"))));
-  if (getenv("GFY_BENCH_KERNEL2")) GK(gfy_encoder_set_option(enc, GFY_OPT_LAYER_KERNEL, 2));
   // graph: records of L nodes: backbone both ways, skip2 both ways, random matching both ways
   const int64_t recs = N / L;
   std::vector<int32_t> src, dst; std::vector<uint8_t> typ;
@@ -144,15 +142,15 @@ int main(int argc, char** argv) {
     gfy_debug_stamps(&st[0][0], 0);
     double sum[16] = {0};
     for (int b = 0; b < 256; ++b) for (int k = 0; k < 16; ++k) sum[k] += (double)st[b][k];
-    if (!getenv("GFY_BENCH_KERNEL2")) {   // third-generation kernel: one wave per tile
+    {
       const double plain = sum[11], headed = sum[13], all = plain + headed;
-      const char* names[10] = {"plan+own rows (hop 1)", "far rows DMA + wait (hop 2)", "barrier 1",
+      const char* names[10] = {"plan + own rows (hop 1)", "far rows DMA + wait (hop 2)", "barrier 1",
                                "gather", "W0 over own stage + barrier 2", "GEMM1 + BatchNorm",
                                "W1 wait + barrier 3", "GEMM2", "LayerNorm + store", "head + normalise"};
-      printf("layer3 phases, shader cycles per launch (wave 0 of each workgroup, mean):\n");
-      for (int k = 0; k < 9; ++k) printf("  %-28s %8.0f\n", names[k], sum[k] / all);
-      printf("  %-28s %8.0f (last launch only)\n", names[9], sum[9] / headed);
-      printf("  GEMM1 split: MFMA blocks %.0f | epilogues %.0f\n", sum[14] / all, sum[15] / all);
+      printf("layer kernel phases, shader cycles per launch (wave 0 of each workgroup, mean):\n");
+      for (int k = 0; k < 9; ++k) printf("  %-30s %8.0f\n", names[k], sum[k] / all);
+      printf("  %-30s %8.0f (last launch only)\n", names[9], sum[9] / headed);
+      printf("  GEMM1: time inside the four BatchNorm epilogues: wave 0 %.0f, wave 4 %.0f\n", sum[14] / all, sum[15] / all);
       printf("  whole wave: %.0f cycles (plain layer), %.0f (with head)\n", sum[10] / plain, sum[12] / headed);
       static unsigned long long real[512][2];
       gfy_debug_real(&real[0][0]);
@@ -168,40 +166,7 @@ int main(int argc, char** argv) {
         printf("last layer launch, real time (100 MHz): %d workgroups, first start -> last start %.2f us, "
                "first end %.2f us, last end %.2f us after the first start\n",
                used, (b1 - b0) / 100.0, (e0 - b0) / 100.0, (e1 - b0) / 100.0);
-      gfy_encoder_destroy(enc);
-      return 0;
     }
-    {
-      const double launches = reps * 4.0 * 256;   // 4 layers, first 256 workgroups
-      double tmax = 0, tmin = 1e30;
-      for (int b = 0; b < 256; ++b) { tmax = st[b][7] > tmax ? st[b][7] : tmax; tmin = st[b][7] < tmin ? st[b][7] : tmin; }
-      printf("per workgroup launch: prologue %.0f cycles, whole kernel body %.0f cycles (min WG %.0f, max WG %.0f per launch)\n",
-             sum[6] / launches, sum[7] / launches, tmin / (reps * 4.0), tmax / (reps * 4.0));
-    }
-    {
-      static unsigned long long real[512][2];
-      gfy_debug_real(&real[0][0]);
-      unsigned long long b0 = ~0ull, b1 = 0, e0 = ~0ull, e1 = 0;
-      int used = 0;
-      for (int b = 0; b < 512; ++b) {
-        if (!real[b][1]) continue;
-        ++used;
-        b0 = real[b][0] < b0 ? real[b][0] : b0; b1 = real[b][0] > b1 ? real[b][0] : b1;
-        e0 = real[b][1] < e0 ? real[b][1] : e0; e1 = real[b][1] > e1 ? real[b][1] : e1;
-      }
-      if (used)
-        printf("last layer launch, real time (100 MHz): %d workgroups, first start -> last start %.2f us, "
-               "first end %.2f us, last end %.2f us after the first start\n",
-               used, (b1 - b0) / 100.0, (e0 - b0) / 100.0, (e1 - b0) / 100.0);
-    }
-    if (sum[8] > 0)
-      printf("  B split: z reads + MFMA issue %.0f | look-ahead issue %.0f | epilogue+barrier %.0f ;  C split: MFMA issue %.0f | epilogue %.0f | - %.0f | barrier %.0f ;  D split: final dma wait %.0f | LN+store+barrier %.0f\n",
-             sum[8] / sum[5], sum[9] / sum[5], sum[10] / sum[5], sum[11] / sum[5], sum[12] / sum[5],
-             sum[13] / sum[5], sum[14] / sum[5], sum[15] / sum[5], (sum[4] - sum[15]) / sum[5]);
-    const double tiles = sum[5];
-    printf("layer-kernel phases, shader cycles per tile (mean over %d tiles): gather %.0f | A->B barrier wait %.0f | GEMM1 %.0f | GEMM2 %.0f | LN+store %.0f | total %.0f\n",
-           (int)tiles, sum[0] / tiles, sum[1] / tiles, sum[2] / tiles, sum[3] / tiles, sum[4] / tiles,
-           (sum[0] + sum[1] + sum[2] + sum[3] + sum[4]) / tiles);
   }
 #endif
   gfy_encoder_destroy(enc);
