@@ -17,7 +17,7 @@ GFY_ERR_INVALID, GFY_ERR_UNSUPPORTED, GFY_ERR_HIP, GFY_ERR_WORKSPACE = 1, 2, 3, 
 GFY_F16, GFY_F32, GFY_F64 = 0, 1, 2
 GFY_L2, GFY_COSINE = 0, 1
 GFY_OPT_SEPARATE_HEAD = 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 #: every symbol include/gfy.h declares: (restype, argtypes)
 SIGNATURES: dict[str, tuple] = {
@@ -40,6 +40,12 @@ SIGNATURES: dict[str, tuple] = {
     "gfy_encode_hidden": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_int64, c_int64, c_int, c_void_p,
                                   c_void_p, c_size_t, c_void_p]),
+    "gfy_encode_coo_workspace_bytes": (c_size_t, [c_void_p, c_int64, c_int64]),
+    "gfy_encode_coo_clear_bytes": (c_size_t, [c_int64]),
+    "gfy_encode_coo_prepare": (c_int, [c_void_p, c_size_t, c_int64, c_void_p]),
+    "gfy_encode_coo": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                               c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t,
+                               c_void_p]),
     "gfy_encoder_set_timing": (c_int, [c_void_p, c_int]),
     "gfy_encoder_set_option": (c_int, [c_void_p, c_int, c_int]),
     "gfy_encoder_get_timing": (c_int, [c_void_p, c_void_p, c_int,

@@ -289,8 +289,8 @@ class Ginfinity:
                 bases, marks, node_ptr, edge_ptr, positional, n1 - n0, e1 - e0,
                 struct_states=1 if spec.struct_feature == "A" else 3,
                 skip2=spec.has_skip2)
-            csr = engine.build_csr(edge_index, edge_types, n1 - n0)
-            block = engine.encode(features, csr, out_dtype=torch_dtype, normalise=True)
+            block = engine.encode_coo(features, edge_index, edge_types, out_dtype=torch_dtype,
+                                      normalise=True)
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(device))
             verdicts.append((start, first_invalid))
@@ -364,6 +364,14 @@ class Ginfinity:
             # a GraphShard per micro-batch: that was 11 of this thread's 15 ms
             n0, n1 = int(shard.node_ptr[start]), int(shard.node_ptr[stop])
             e0, e1 = int(shard.edge_ptr[start]), int(shard.edge_ptr[stop])
+            # ... except the one check of GraphShard.__post_init__ that depends on the slice
+            # (graph.py:318-321 after the rebasing of 414-444): an edge that leaves the
+            # micro-batch's node range — an edge across graphs that the whole-shard range
+            # check cannot see — is refused exactly as the reference refuses it
+            if e1 > e0:
+                window = shard.edge_index[:, e0:e1]
+                if int(window.min()) < n0 or int(window.max()) >= n1:
+                    raise GraphValidationError("edge index outside shard node range")
             roles = shard.node_roles[n0:n1]
             rows, kept = None, n1 - n0
             if roles.any():                      # context nodes: dropped at the head's store
@@ -374,9 +382,9 @@ class Ginfinity:
             features, edge_index, edge_types, out_rows = self._uploader(
                 (shard.node_features[n0:n1], shard.edge_index[:, e0:e1] - np.int32(n0),
                  shard.edge_types[e0:e1], rows))
-            csr = self._engine.build_csr(edge_index, edge_types, n1 - n0)
-            block = self._engine.encode(features, csr, out_rows=out_rows, n_out=kept,
-                                        out_dtype=torch_dtype, normalise=True)
+            block = self._engine.encode_coo(features, edge_index, edge_types,
+                                            out_rows=out_rows, n_out=kept,
+                                            out_dtype=torch_dtype, normalise=True)
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(block.device))
             pending.append(self._copier.submit(

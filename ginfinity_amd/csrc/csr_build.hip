@@ -7,18 +7,21 @@
 // (oracle/gine_numpy.py:build_csr) and identical from run to run.
 //
 // Pipeline (all on one stream, no host sync):
-//   1 histogram   slot[e] = atomicAdd(count[dst[e]], 1)      (arbitrary rank)
-//   2 scan        row_ptr = exclusive_scan(count)            (1 kernel up to 131,072 nodes)
-//   3 scatter     perm[row_ptr[dst[e]] + slot[e]] = e
-//   4 sort rows   each row's edge ids ascending -> COO order restored, then
-//                 col/typ gathered through perm.  Rows longer than kSmallRow are
-//                 handed to the whole workgroup (rank sort) in the same launch.
-// RNA graphs have in-degree <= 5, so step 4 is a 5-element
-// insertion sort per thread; the worklist path keeps arbitrary interchange
-// shards (hubs, degree in the thousands) correct.
+//   1 count    slot = atomicAdd(count[dst[e]], 1); the first kCsrSlots ids of a row go to
+//              table[dst][slot], later ones to one overflow list       (arbitrary order)
+//   2 scan     row_ptr = exclusive_scan(count)              (1 kernel up to 131,072 nodes)
+//   3 finish   per row: rank of every id among the row's ids = its CSR position, col/typ
+//              gathered through it; hub rows by the whole block (csr_finish.inc).  The
+//              counters are left zero again.
+// RNA graphs have in-degree <= 6, so every row is finished from its eight table
+// entries; the overflow path keeps arbitrary interchange shards (hubs, degree in the
+// thousands) correct.  Round 1 ran five launches (zero, histogram, scan, scatter, sort); a
+// dependent launch costs ~4.5 us of stream time whatever it does, and the fused per-encode
+// setup (gine_f16.hip) runs stage 3 together with the tile plans and the input Linear.
 #include "gfy_common.h"
 
 namespace gfy {
+#include "csr_finish.inc"
 namespace {
 
 constexpr int kScanBlock = 256;
@@ -27,14 +30,40 @@ constexpr int kScanTile = kScanBlock * kScanItems;
 constexpr int kSmallRow = 32;
 constexpr int kDirectScanTiles = 64;   // up to here every scan block sums its own prefix
 
-__global__ __launch_bounds__(256) void k_histogram(
-    const int32_t* __restrict__ dst, int64_t e_count, int64_t n,
-    int32_t* __restrict__ count, int32_t* __restrict__ slot) {
-  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; e < e_count; e += stride) {
+constexpr int kCountEdgesPerBlock = 1024;   // 4 per thread
+
+// kTileSums: also leave the number of edges per 32 destination rows (what the scan-free finish
+// sums).  One global atomic per edge would double the kernel (300 k more atomics: 6.5 -> 12 us,
+// and 86 us when the 32 edges of a backbone run hit one address from one wave): the block
+// counts its 1,024 edges per tile in LDS first and adds the non-zero bins.
+template <bool kTileSums>
+__global__ __launch_bounds__(256) void k_csr_count(
+    const int32_t* __restrict__ dst, int64_t e_count, int64_t n, int32_t* __restrict__ count,
+    int32_t* __restrict__ table, int32_t* __restrict__ overflow,
+    int32_t* __restrict__ overflow_count, int32_t* __restrict__ tile_sum, int tiles) {
+  __shared__ int s_bins[kTileSums ? kCsrLocalScanTiles : 1];
+  if constexpr (kTileSums) {
+    for (int i = threadIdx.x; i < tiles; i += 256) s_bins[i] = 0;
+    __syncthreads();
+  }
+  const int64_t first = (int64_t)blockIdx.x * kCountEdgesPerBlock;
+#pragma unroll
+  for (int k = 0; k < kCountEdgesPerBlock / 256; ++k) {
+    const int64_t e = first + k * 256 + threadIdx.x;
+    if (e >= e_count) continue;
     const int32_t d = dst[e];
-    slot[e] = ((uint32_t)d < (uint64_t)n) ? atomicAdd(&count[d], 1) : -1;
+    if ((uint32_t)d >= (uint64_t)n) continue;   // not an edge of this shard: not in any row
+    const int slot = atomicAdd(&count[d], 1);
+    if (slot < kCsrSlots) table[(size_t)d * kCsrSlots + slot] = (int32_t)e;
+    else overflow[atomicAdd(overflow_count, 1)] = (int32_t)e;
+    if constexpr (kTileSums) atomicAdd(&s_bins[d / kCsrTileRows], 1);
+  }
+  if constexpr (kTileSums) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < tiles; i += 256) {
+      const int edges = s_bins[i];
+      if (edges) atomicAdd(&tile_sum[i], edges);
+    }
   }
 }
 
@@ -168,94 +197,14 @@ __global__ __launch_bounds__(256) void k_zero(int32_t* __restrict__ count, int64
   for (; i < items; i += stride) count[i] = 0;
 }
 
-__global__ __launch_bounds__(256) void k_scatter(
-    const int32_t* __restrict__ dst, const int32_t* __restrict__ slot,
-    const int32_t* __restrict__ row_ptr, int64_t e_count,
-    int32_t* __restrict__ perm) {
-  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; e < e_count; e += stride) {
-    const int32_t s = slot[e];
-    if (s >= 0) perm[row_ptr[dst[e]] + s] = (int32_t)e;
-  }
-}
-
-__global__ __launch_bounds__(256) void k_sort_rows(
-    const int32_t* __restrict__ row_ptr, int64_t n, int32_t* __restrict__ perm,
-    const int32_t* __restrict__ src, const uint8_t* __restrict__ types,
+// stage 3 on its own (gfy_build_csr); the fused setup of gine_f16.hip has the same body
+template <bool kScanned>
+__global__ __launch_bounds__(256) void k_csr_finish(
+    const CsrScratch w, int32_t* __restrict__ row_ptr, const int32_t* __restrict__ src,
+    const int32_t* __restrict__ dst, const uint8_t* __restrict__ types, int n,
     int32_t* __restrict__ col, uint8_t* __restrict__ typ) {
-  __shared__ int big_rows[256];
-  __shared__ int big_count;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t first = (int64_t)blockIdx.x * blockDim.x; first < n; first += stride) {
-    if (threadIdx.x == 0) big_count = 0;
-    __syncthreads();
-    const int64_t row = first + threadIdx.x;
-    if (row < n) {
-      const int32_t lo = row_ptr[row], hi = row_ptr[row + 1];
-      if (hi - lo > kSmallRow) {
-        big_rows[atomicAdd(&big_count, 1)] = (int32_t)row;
-      } else {
-        // insertion sort of the edge ids (tiny, L1/L2 resident)
-        for (int32_t i = lo + 1; i < hi; ++i) {
-          const int32_t key = perm[i];
-          int32_t j = i - 1;
-          while (j >= lo) {
-            const int32_t p = perm[j];
-            if (p <= key) break;
-            perm[j + 1] = p;
-            --j;
-          }
-          perm[j + 1] = key;
-        }
-        for (int32_t i = lo; i < hi; ++i) {
-          const int32_t edge = perm[i];
-          col[i] = src[edge];
-          typ[i] = types[edge];
-        }
-      }
-    }
-    __syncthreads();
-    // rows above kSmallRow: the whole workgroup, rank sort (edge ids are distinct)
-    const int rows = big_count;
-    for (int w = 0; w < rows; ++w) {
-      const int32_t big = big_rows[w];
-      const int32_t lo = row_ptr[big], deg = row_ptr[big + 1] - lo;
-      for (int32_t i = threadIdx.x; i < deg; i += blockDim.x) {
-        const int32_t key = perm[lo + i];
-        int32_t rank = 0;
-        for (int32_t j = 0; j < deg; ++j) rank += perm[lo + j] < key;
-        col[lo + rank] = src[key];
-        typ[lo + rank] = types[key];
-      }
-    }
-    __syncthreads();
-  }
-}
-
-struct CsrWorkspace {
-  int32_t* count;     // [N + 1] in-degree counters (16-byte aligned, read as int4)
-  int32_t* slot;      // [E]
-  int32_t* perm;      // [E]
-  int32_t* sums;      // [tiles]
-  size_t bytes;
-};
-
-CsrWorkspace carve(void* base, int64_t n, int64_t e) {
-  const int64_t tiles = (n + kScanTile - 1) / kScanTile + 1;
-  size_t off = 0;
-  auto take = [&](size_t bytes) {
-    void* p = base ? (char*)base + off : nullptr;
-    off += align_up(bytes, 256);
-    return p;
-  };
-  CsrWorkspace w;
-  w.count = (int32_t*)take((size_t)(n + 1) * 4);
-  w.slot = (int32_t*)take((size_t)e * 4);
-  w.perm = (int32_t*)take((size_t)e * 4);
-  w.sums = (int32_t*)take((size_t)tiles * 4);
-  w.bytes = off;
-  return w;
+  csr_finish_tile<kScanned>(w, row_ptr, src, dst, types, n, blockIdx.x, col, typ);
+  csr_finish_release(w, gridDim.x);
 }
 
 int grid_for(int64_t items, int block, int cap = 2048) {
@@ -266,7 +215,75 @@ int grid_for(int64_t items, int block, int cap = 2048) {
 
 }  // namespace
 
-size_t csr_workspace_bytes(int64_t n, int64_t e) { return carve(nullptr, n, e).bytes; }
+// The counters come first: csr_clear_bytes() bytes at the start of the workspace are what has
+// to be zero when a build starts (and is zero again when it ends).
+static int64_t finish_tiles(int64_t n) { return (n + kCsrTileRows - 1) / kCsrTileRows; }
+size_t csr_clear_bytes(int64_t n) {
+  return align_up((size_t)(n + 1) * 4, 256) + 256 + align_up((size_t)finish_tiles(n) * 4, 256);
+}
+bool csr_scan_free(int64_t n) { return finish_tiles(n) <= kCsrLocalScanTiles; }
+
+CsrScratch carve_csr(void* base, int64_t n, int64_t e, int32_t** sums, size_t* bytes) {
+  const int64_t tiles = (n + kScanTile - 1) / kScanTile + 1;
+  size_t off = 0;
+  auto take = [&](size_t size) {
+    void* p = base ? (char*)base + off : nullptr;
+    off += align_up(size, 256);
+    return p;
+  };
+  CsrScratch w;
+  w.count = (int32_t*)take((size_t)(n + 1) * 4);
+  w.overflow_count = (int32_t*)take(256);
+  w.tile_sum = (int32_t*)take((size_t)finish_tiles(n) * 4);
+  w.table = (int32_t*)take((size_t)n * kCsrSlots * 4);
+  w.overflow = (int32_t*)take((size_t)e * 4);
+  w.perm = (int32_t*)take((size_t)e * 4);
+  int32_t* scan_sums = (int32_t*)take((size_t)tiles * 4);
+  if (sums) *sums = scan_sums;
+  if (bytes) *bytes = off;
+  return w;
+}
+
+size_t csr_workspace_bytes(int64_t n, int64_t e) {
+  size_t bytes = 0;
+  carve_csr(nullptr, n, e, nullptr, &bytes);
+  return bytes;
+}
+
+int launch_csr_clear(void* ws, int64_t n, hipStream_t s) {
+  const int64_t items = (int64_t)(csr_clear_bytes(n) / 4);
+  k_zero<<<grid_for(items, 256, 1024), 256, 0, s>>>((int32_t*)ws, items);
+  GFY_CHECK_HIP(hipGetLastError());
+  return GFY_OK;
+}
+
+// stages 1 and 2 (the counters must be zero).  Shards of up to 131,072 nodes need no scan
+// launch: the finish stage sums the per-tile edge counts in front of its tile itself.
+int launch_csr_count_scan(const CsrScratch& w, int32_t* sums, const int32_t* edge_index,
+                          int64_t n, int64_t e, int32_t* row_ptr, hipStream_t s) {
+  const int32_t* dst = edge_index + e;
+  const bool local = csr_scan_free(n);
+  const int blocks = (int)((e + kCountEdgesPerBlock - 1) / kCountEdgesPerBlock);
+  if (e > 0 && local)
+    k_csr_count<true><<<blocks, 256, 0, s>>>(dst, e, n, w.count, w.table, w.overflow,
+                                             w.overflow_count, w.tile_sum, (int)finish_tiles(n));
+  else if (e > 0)
+    k_csr_count<false><<<blocks, 256, 0, s>>>(dst, e, n, w.count, w.table, w.overflow,
+                                              w.overflow_count, nullptr, 0);
+  if (!local) {
+    const int tiles = (int)((n + kScanTile - 1) / kScanTile);
+    if (tiles <= kDirectScanTiles) {
+      k_scan_final<<<tiles, kScanBlock, 0, s>>>(w.count, row_ptr, n, nullptr);
+    } else {
+      // (a single-pass chained scan was measured slower: 17 us, profiles/README.md)
+      k_scan_partial<<<tiles, kScanBlock, 0, s>>>(w.count, n, sums);
+      k_scan_sums<<<1, kScanBlock, 0, s>>>(sums, tiles);
+      k_scan_final<<<tiles, kScanBlock, 0, s>>>(w.count, row_ptr, n, sums);
+    }
+  }
+  GFY_CHECK_HIP(hipGetLastError());
+  return GFY_OK;
+}
 
 int launch_build_csr(const int32_t* edge_index, const uint8_t* edge_types,
                      int64_t n, int64_t e, int32_t* row_ptr, int32_t* col,
@@ -274,29 +291,23 @@ int launch_build_csr(const int32_t* edge_index, const uint8_t* edge_types,
   GFY_REQUIRE(n > 0 && n < INT32_MAX && e >= 0 && e < INT32_MAX, GFY_ERR_INVALID,
               "gfy_build_csr: node/edge counts must fit int32 (n=%lld e=%lld)",
               (long long)n, (long long)e);
-  const CsrWorkspace w = carve(ws, n, e);
-  GFY_REQUIRE(ws_bytes >= w.bytes, GFY_ERR_WORKSPACE,
-              "gfy_build_csr: workspace %zu < required %zu", ws_bytes, w.bytes);
-  const int32_t* src = edge_index;
-  const int32_t* dst = edge_index + e;
-  const int tiles = (int)((n + kScanTile - 1) / kScanTile);
-
-  // five launches: zero, histogram, scan, scatter, sort
-  k_zero<<<grid_for(n + 1, 256, 1024), 256, 0, s>>>(w.count, n + 1);
-  if (e > 0)
-    k_histogram<<<grid_for(e, 256), 256, 0, s>>>(dst, e, n, w.count, w.slot);
-  if (tiles <= kDirectScanTiles) {
-    k_scan_final<<<tiles, kScanBlock, 0, s>>>(w.count, row_ptr, n, nullptr);
-  } else {
-    // (a single-pass chained scan was measured slower: 17 us, profiles/README.md)
-    k_scan_partial<<<tiles, kScanBlock, 0, s>>>(w.count, n, w.sums);
-    k_scan_sums<<<1, kScanBlock, 0, s>>>(w.sums, tiles);
-    k_scan_final<<<tiles, kScanBlock, 0, s>>>(w.count, row_ptr, n, w.sums);
-  }
-  if (e > 0) {
-    k_scatter<<<grid_for(e, 256), 256, 0, s>>>(dst, w.slot, row_ptr, e, w.perm);
-    k_sort_rows<<<grid_for(n, 256), 256, 0, s>>>(row_ptr, n, w.perm, src, edge_types, col, typ);
-  }
+  int32_t* sums = nullptr;
+  size_t need = 0;
+  const CsrScratch w = carve_csr(ws, n, e, &sums, &need);
+  GFY_REQUIRE(ws_bytes >= need, GFY_ERR_WORKSPACE,
+              "gfy_build_csr: workspace %zu < required %zu", ws_bytes, need);
+  // this entry point takes any scratch memory, so it clears the counters itself: four
+  // launches, three without a scan (gfy_encode_coo on a cleared workspace: two, stage 3 fused
+  // with the setup)
+  if (const int rc = launch_csr_clear(ws, n, s)) return rc;
+  if (const int rc = launch_csr_count_scan(w, sums, edge_index, n, e, row_ptr, s)) return rc;
+  const int tiles = (int)finish_tiles(n);
+  if (csr_scan_free(n))
+    k_csr_finish<false><<<tiles, 256, 0, s>>>(w, row_ptr, edge_index, edge_index + e, edge_types,
+                                              (int)n, col, typ);
+  else
+    k_csr_finish<true><<<tiles, 256, 0, s>>>(w, row_ptr, edge_index, edge_index + e, edge_types,
+                                             (int)n, col, typ);
   GFY_CHECK_HIP(hipGetLastError());
   return GFY_OK;
 }

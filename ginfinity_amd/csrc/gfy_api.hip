@@ -536,6 +536,64 @@ static int encode_common(gfy_encoder* enc, const float* x, const int32_t* row_pt
                            (hipStream_t)stream);
 }
 
+size_t gfy_encode_coo_clear_bytes(int64_t n) { return csr_clear_bytes(n < 1 ? 1 : n); }
+
+size_t gfy_encode_coo_workspace_bytes(const gfy_encoder* enc, int64_t n, int64_t e) {
+  if (!enc) return 0;
+  n = n < 1 ? 1 : n;
+  e = e < 0 ? 0 : e;
+  if (enc->model_dtype == GFY_F16) return encode_coo_f16_workspace_bytes(n, e);
+  // fp32 model: plain sequence (CSR build, then encode), CSR arrays in front
+  return align_up(csr_workspace_bytes(n, e), 256) + align_up((size_t)(n + 1) * 4, 256) +
+         align_up((size_t)(e > 0 ? e : 1) * 4, 256) + align_up((size_t)(e > 0 ? e : 1), 256) +
+         encode_f32_workspace_bytes(n, e);
+}
+
+int gfy_encode_coo_prepare(void* ws, size_t ws_bytes, int64_t n, void* stream) {
+  clear_error();
+  GFY_REQUIRE(ws && n > 0 && n < INT32_MAX, GFY_ERR_INVALID, "gfy_encode_coo_prepare: bad arguments");
+  GFY_REQUIRE(ws_bytes >= csr_clear_bytes(n), GFY_ERR_WORKSPACE,
+              "gfy_encode_coo_prepare: workspace %zu < %zu", ws_bytes, csr_clear_bytes(n));
+  return launch_csr_clear(ws, n, (hipStream_t)stream);
+}
+
+int gfy_encode_coo(gfy_encoder* enc, const float* x, const int32_t* edge_index,
+                   const uint8_t* edge_types, int64_t n, int64_t e, const int32_t* out_rows,
+                   void* out, int out_dtype, int normalise, void* ws, size_t ws_bytes,
+                   void* stream) {
+  clear_error();
+  GFY_REQUIRE(enc != nullptr, GFY_ERR_INVALID, "gfy_encode_coo: encoder is NULL");
+  GFY_REQUIRE(n > 0 && n < INT32_MAX && e >= 0 && e < INT32_MAX, GFY_ERR_INVALID,
+              "gfy_encode_coo: n=%lld e=%lld out of range", (long long)n, (long long)e);
+  GFY_REQUIRE(x && out && ws, GFY_ERR_INVALID, "gfy_encode_coo: NULL argument");
+  GFY_REQUIRE(e == 0 || (edge_index && edge_types), GFY_ERR_INVALID,
+              "gfy_encode_coo: NULL edge array with E=%lld", (long long)e);
+  GFY_REQUIRE(out_dtype == GFY_F16 || out_dtype == GFY_F32 || out_dtype == GFY_F64,
+              GFY_ERR_INVALID, "gfy_encode_coo: unsupported out_dtype %d", out_dtype);
+  const size_t need = gfy_encode_coo_workspace_bytes(enc, n, e);
+  GFY_REQUIRE(ws_bytes >= need, GFY_ERR_WORKSPACE, "gfy_encode_coo: workspace %zu < required %zu",
+              ws_bytes, need);
+  if (enc->model_dtype == GFY_F16)
+    return launch_encode_coo_f16(enc, x, edge_index, edge_types, n, e, out_rows, out, out_dtype,
+                                 normalise, ws, ws_bytes, (hipStream_t)stream);
+  // fp32 model (parity path, MFMA-bound): the two calls behind one entry point
+  char* at = (char*)ws;
+  void* csr_ws = at;
+  const size_t csr_bytes = align_up(csr_workspace_bytes(n, e), 256);
+  at += csr_bytes;
+  int32_t* row_ptr = (int32_t*)at;
+  at += align_up((size_t)(n + 1) * 4, 256);
+  int32_t* col = (int32_t*)at;
+  at += align_up((size_t)(e > 0 ? e : 1) * 4, 256);
+  uint8_t* typ = (uint8_t*)at;
+  at += align_up((size_t)(e > 0 ? e : 1), 256);
+  if (const int rc = launch_build_csr(edge_index, edge_types, n, e, row_ptr, col, typ, csr_ws,
+                                      csr_bytes, (hipStream_t)stream))
+    return rc;
+  return launch_encode_f32(enc, x, row_ptr, col, typ, n, e, out_rows, out, out_dtype, normalise,
+                           -1, at, ws_bytes - (size_t)(at - (char*)ws), (hipStream_t)stream);
+}
+
 int gfy_encode(gfy_encoder* enc, const float* x, const int32_t* row_ptr,
                const int32_t* col, const uint8_t* typ, int64_t n, int64_t e,
                const int32_t* out_rows, void* out, int out_dtype, int normalise,

@@ -161,6 +161,25 @@ struct gfy_encoder {
 // ---- kernel launchers (one per .hip file) -------------------------------------------
 namespace gfy {
 
+// COO -> CSR scratch (csr_build.hip, csr_finish.inc), all in the caller's workspace
+constexpr int kCsrSlots = 8;        // edge ids kept per row in the table (= plan slots)
+constexpr int kCsrTileRows = 32;    // rows finished by one 256-thread block (= layer tile)
+constexpr int kCsrLocalScanTiles = 4096;   // up to here the finish stage derives row_ptr itself
+struct CsrScratch {
+  int32_t* count;              // [n + 1]   in-degree counters          (zero between calls)
+  int32_t* overflow_count;     // [2]       list length, finish ticket  (zero between calls)
+  int32_t* tile_sum;           // [tiles]   edges per 32 rows           (zero between calls)
+  int32_t* table;              // [n][kCsrSlots] first edge ids of every row
+  int32_t* overflow;           // [e]       edge ids that found their row's slots taken
+  int32_t* perm;               // [e]       hub rows: ids collected for the rank sort
+};
+size_t csr_clear_bytes(int64_t n);   // leading bytes of the workspace that must be zero
+bool csr_scan_free(int64_t n);       // the finish stage derives row_ptr itself
+CsrScratch carve_csr(void* base, int64_t n, int64_t e, int32_t** scan_sums, size_t* bytes);
+int launch_csr_clear(void* ws, int64_t n, hipStream_t s);
+int launch_csr_count_scan(const CsrScratch& w, int32_t* scan_sums, const int32_t* edge_index,
+                          int64_t n, int64_t e, int32_t* row_ptr, hipStream_t s);
+
 int launch_build_csr(const int32_t* edge_index, const uint8_t* edge_types,
                      int64_t n, int64_t e, int32_t* row_ptr, int32_t* col,
                      uint8_t* typ, void* ws, size_t ws_bytes, hipStream_t s);
@@ -179,6 +198,14 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
                       int normalise, int tap_stage, void* ws, size_t ws_bytes,
                       hipStream_t s);
 size_t encode_f16_workspace_bytes(int64_t n, int64_t e);
+// COO in -> embeddings out: CSR build and encode as one sequence of launches, the last CSR
+// stage fused with the per-encode setup; the workspace's first csr_clear_bytes(n) bytes must
+// be zero (they are zero again afterwards)
+int launch_encode_coo_f16(const gfy_encoder* enc, const float* x, const int32_t* edge_index,
+                          const uint8_t* edge_types, int64_t n, int64_t e,
+                          const int32_t* out_rows, void* out, int out_dtype, int normalise,
+                          void* ws, size_t ws_bytes, hipStream_t s);
+size_t encode_coo_f16_workspace_bytes(int64_t n, int64_t e);
 
 int launch_encode_f32(const gfy_encoder* enc, const float* x,
                       const int32_t* row_ptr, const int32_t* col,

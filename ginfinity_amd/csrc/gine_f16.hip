@@ -386,6 +386,7 @@ __global__ __launch_bounds__(256) void k_copy_rows_f16(const f16* __restrict__ s
   }
 }
 
+#include "csr_finish.inc"
 #include "gine_layer.inc"
 
 int persistent_grid(int num_tiles) {
@@ -443,12 +444,22 @@ static int opt_in_layer_lds() {
   });
 }
 
-int launch_encode_f16(const gfy_encoder* enc, const float* x,
-                      const int32_t* row_ptr, const int32_t* col,
-                      const uint8_t* typ, int64_t n, int64_t e,
-                      const int32_t* out_rows, void* out, int out_dtype,
-                      int normalise, int tap_stage, void* ws, size_t ws_bytes,
-                      hipStream_t s) {
+// `coo` != nullptr: the CSR is finished inside the setup launch (gfy_encode_coo)
+struct CooInput {
+  CsrScratch scratch;
+  const int32_t* edge_index;
+  const uint8_t* edge_types;
+  int64_t e;
+  int32_t* row_ptr;
+  int32_t* col;
+  uint8_t* typ;
+};
+
+static int encode_f16_on(const gfy_encoder* enc, const float* x, const int32_t* row_ptr,
+                         const int32_t* col, const uint8_t* typ, const CooInput* coo, int64_t n,
+                         const int32_t* out_rows, void* out, int out_dtype, int normalise,
+                         int tap_stage, void* ws, size_t ws_bytes, hipStream_t s) {
+  const int64_t e = 0;
   (void)e;
   const size_t need = encode_f16_workspace_bytes(n, e);
   GFY_REQUIRE(ws_bytes >= need, GFY_ERR_WORKSPACE,
@@ -473,7 +484,17 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
     if (tap_stage == 0)
       k_input_linear_f16<<<linear_blocks, 256, 0, s>>>(x, enc->f16.w_in, enc->f16.b_in, ha,
                                                        (int)n);
-    else   // + tile plans, once for all layers, in the same launch
+    else if (coo && csr_scan_free(n))   // + last CSR stage (row offsets included) + tile plans
+      k_encode_setup_coo<false><<<layer_tiles + linear_blocks, 256, 0, s>>>(
+          x, enc->f16.w_in, enc->f16.b_in, ha, (int)n, coo->scratch, coo->row_ptr,
+          coo->edge_index, coo->edge_index + coo->e, coo->edge_types, coo->col, coo->typ, plans,
+          layer_tiles);
+    else if (coo)
+      k_encode_setup_coo<true><<<layer_tiles + linear_blocks, 256, 0, s>>>(
+          x, enc->f16.w_in, enc->f16.b_in, ha, (int)n, coo->scratch, coo->row_ptr,
+          coo->edge_index, coo->edge_index + coo->e, coo->edge_types, coo->col, coo->typ, plans,
+          layer_tiles);
+    else            // + tile plans
       k_encode_setup<<<layer_tiles + linear_blocks, 256, 0, s>>>(
           x, enc->f16.w_in, enc->f16.b_in, ha, (int)n, row_ptr, col, typ, plans, layer_tiles);
   }
@@ -489,7 +510,8 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
 #define GFY_LAUNCH_LAYER(RES, HEAD)                                                          \
   k_gine_layer_f16<RES, HEAD><<<layer_grid, kLThreads, kLdsBytes, s>>>(                      \
       enc->f16.layer[l], ha, hb, row_ptr, col, typ, plans, (int)n, layer_tiles, enc->f16.head, \
-      out_rows, (f16*)out, normalise)
+      out_rows, (f16*)out, normalise,                                                        \
+      coo && l == 0 && csr_scan_free(n) ? coo->scratch.tile_sum : nullptr)
     if (enc->residual && with_head) GFY_LAUNCH_LAYER(true, true);
     else if (enc->residual) GFY_LAUNCH_LAYER(true, false);
     else if (with_head) GFY_LAUNCH_LAYER(false, true);
@@ -529,6 +551,60 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
   enc->mark(s, 2 + enc->layers);
   GFY_CHECK_HIP(hipGetLastError());
   return GFY_OK;
+}
+
+int launch_encode_f16(const gfy_encoder* enc, const float* x,
+                      const int32_t* row_ptr, const int32_t* col,
+                      const uint8_t* typ, int64_t n, int64_t e,
+                      const int32_t* out_rows, void* out, int out_dtype,
+                      int normalise, int tap_stage, void* ws, size_t ws_bytes,
+                      hipStream_t s) {
+  (void)e;
+  return encode_f16_on(enc, x, row_ptr, col, typ, nullptr, n, out_rows, out, out_dtype,
+                       normalise, tap_stage, ws, ws_bytes, s);
+}
+
+// workspace of gfy_encode_coo: [CSR scratch, counters first][row_ptr][col][typ][encode]
+struct CooWorkspace {
+  CsrScratch scratch;
+  int32_t* scan_sums;
+  int32_t* row_ptr;
+  int32_t* col;
+  uint8_t* typ;
+  void* encode;
+  size_t encode_bytes, bytes;
+};
+static CooWorkspace carve_coo(void* base, int64_t n, int64_t e) {
+  CooWorkspace w;
+  size_t off = 0;
+  w.scratch = carve_csr(base, n, e, &w.scan_sums, &off);
+  auto take = [&](size_t size) {
+    void* p = base ? (char*)base + off : nullptr;
+    off += align_up(size, 256);
+    return p;
+  };
+  w.row_ptr = (int32_t*)take((size_t)(n + 1) * 4);
+  w.col = (int32_t*)take((size_t)(e > 0 ? e : 1) * 4);
+  w.typ = (uint8_t*)take((size_t)(e > 0 ? e : 1));
+  w.encode_bytes = encode_f16_workspace_bytes(n, e);
+  w.encode = take(w.encode_bytes);
+  w.bytes = off;
+  return w;
+}
+size_t encode_coo_f16_workspace_bytes(int64_t n, int64_t e) { return carve_coo(nullptr, n, e).bytes; }
+
+int launch_encode_coo_f16(const gfy_encoder* enc, const float* x, const int32_t* edge_index,
+                          const uint8_t* edge_types, int64_t n, int64_t e,
+                          const int32_t* out_rows, void* out, int out_dtype, int normalise,
+                          void* ws, size_t ws_bytes, hipStream_t s) {
+  const CooWorkspace w = carve_coo(ws, n, e);
+  GFY_REQUIRE(ws_bytes >= w.bytes, GFY_ERR_WORKSPACE,
+              "gfy_encode_coo: workspace %zu < required %zu", ws_bytes, w.bytes);
+  if (const int rc = launch_csr_count_scan(w.scratch, w.scan_sums, edge_index, n, e, w.row_ptr, s))
+    return rc;
+  const CooInput coo{w.scratch, edge_index, edge_types, e, w.row_ptr, w.col, w.typ};
+  return encode_f16_on(enc, x, w.row_ptr, w.col, w.typ, &coo, n, out_rows, out, out_dtype,
+                       normalise, -1, w.encode, w.encode_bytes, s);
 }
 
 }  // namespace gfy

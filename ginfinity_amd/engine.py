@@ -71,6 +71,10 @@ class DeviceEncoder:
                 index, ctypes.byref(handle)), "gfy_encoder_create")
         self._handle = handle
         self._workspace: torch.Tensor | None = None
+        # gfy_encode_coo's own workspace: its leading counters are zero between calls as long
+        # as nobody else writes to it (include/gfy.h), so it is never shared with _scratch
+        self._coo_workspace: torch.Tensor | None = None
+        self._coo_clean_nodes = 0      # the counters are known to be zero for n <= this
 
     # -- lifetime ---------------------------------------------------------------
     def close(self) -> None:
@@ -179,11 +183,50 @@ class DeviceEncoder:
                 _ptr(scratch), scratch.numel(), self._stream()), "gfy_encode")
         return out
 
+    def encode_coo(self, node_features: torch.Tensor, edge_index: torch.Tensor,
+                   edge_types: torch.Tensor, *, out_rows: torch.Tensor | None = None,
+                   n_out: int | None = None, out_dtype: torch.dtype = torch.float16,
+                   normalise: bool = True, out: torch.Tensor | None = None) -> torch.Tensor:
+        """COO in → [n_out, 128] embeddings on the device: the body of
+        ``Ginfinity._run_graph_shard`` (api.py:236-252) as ONE C-ABI call, the CSR build
+        fused into the encoder's setup (3 + 4 launches for the fp16 model)."""
+        nodes = int(node_features.shape[0])
+        edges = int(edge_types.numel())
+        assert node_features.dtype == torch.float32 and node_features.is_contiguous()
+        assert edge_index.dtype == torch.int32 and edge_index.is_contiguous()
+        assert edge_types.dtype == torch.uint8 and edge_types.is_contiguous()
+        assert tuple(edge_index.shape) == (2, edges)
+        rows = nodes if n_out is None else int(n_out)
+        lib = self._lib
+        with torch.cuda.device(self.device):
+            if out is None:
+                out = torch.empty((rows, EMBEDDING_DIM), dtype=out_dtype, device=self.device)
+            assert out.is_contiguous() and out.shape == (rows, EMBEDDING_DIM)
+            need = lib.gfy_encode_coo_workspace_bytes(self._handle, nodes, edges)
+            if self._coo_workspace is None or self._coo_workspace.numel() < need:
+                self._coo_workspace = torch.zeros(max(need, 1 << 20), dtype=torch.uint8,
+                                                  device=self.device)
+                self._coo_clean_nodes = 1 << 62
+            scratch = self._coo_workspace
+            if nodes > self._coo_clean_nodes:   # an earlier, smaller call's arrays lie where
+                native.check(lib.gfy_encode_coo_prepare(   # this call's counters will be
+                    _ptr(scratch), scratch.numel(), nodes, self._stream()),
+                    "gfy_encode_coo_prepare")
+            self._coo_clean_nodes = 0           # until the call below has been enqueued
+            native.check(lib.gfy_encode_coo(
+                self._handle, _ptr(node_features), _ptr(edge_index) if edges else None,
+                _ptr(edge_types) if edges else None, nodes, edges, _ptr(out_rows), _ptr(out),
+                _GFY_OF_TORCH[out.dtype], 1 if normalise else 0, _ptr(scratch),
+                scratch.numel(), self._stream()), "gfy_encode_coo")
+            self._coo_clean_nodes = nodes
+        return out
+
     def prepare_step(self, node_features: torch.Tensor, edge_index: torch.Tensor,
                      edge_types: torch.Tensor, out: torch.Tensor):
         """CSR build + encode of one device-resident shard as a pre-bound callable
         ``step(stream_handle)``: buffers, workspaces and pointers are resolved once, each
-        call is two C-ABI calls and nothing else.  For steady-state loops over same-sized
+        call is ONE C-ABI call (gfy_encode_coo on a workspace of its own, cleared here) and
+        nothing else.  For steady-state loops over same-sized
         shards (bench.py): per-step Python overhead drops from ~50 us to a few us.  The
         calling thread's current device must be this encoder's device (the C ABI launches on
         the caller's device; ``torch.cuda.set_device`` once, as bench.py does)."""
@@ -193,33 +236,22 @@ class DeviceEncoder:
         assert edge_index.dtype == torch.int32 and tuple(edge_index.shape) == (2, edges)
         assert edge_types.dtype == torch.uint8 and edge_index.is_contiguous()
         assert out.is_contiguous() and tuple(out.shape) == (nodes, EMBEDDING_DIM)
-        with torch.cuda.device(self.device):
-            csr = DeviceCsr(
-                torch.empty(nodes + 1, dtype=torch.int32, device=self.device),
-                torch.empty(max(edges, 1), dtype=torch.int32, device=self.device),
-                torch.empty(max(edges, 1), dtype=torch.uint8, device=self.device),
-                nodes, edges)
-            need = max(self._lib.gfy_csr_workspace_bytes(nodes, edges),
-                       self._lib.gfy_encode_workspace_bytes(self._handle, nodes, edges))
-            scratch = self._scratch(need)
         lib, handle = self._lib, self._handle
-        build, encode = lib.gfy_build_csr, lib.gfy_encode
+        with torch.cuda.device(self.device):
+            need = lib.gfy_encode_coo_workspace_bytes(handle, nodes, edges)
+            scratch = torch.zeros(need, dtype=torch.uint8, device=self.device)   # cleared once
+        encode = lib.gfy_encode_coo
         p_ei = _ptr(edge_index) if edges else None
         p_et = _ptr(edge_types) if edges else None
-        p_x, p_rp, p_col, p_typ = (_ptr(node_features), _ptr(csr.row_ptr), _ptr(csr.col),
-                                   _ptr(csr.typ))
-        p_out, p_ws, ws_bytes = _ptr(out), _ptr(scratch), scratch.numel()
+        p_x, p_out, p_ws, ws_bytes = _ptr(node_features), _ptr(out), _ptr(scratch), scratch.numel()
         out_code = _GFY_OF_TORCH[out.dtype]
-        keep = (node_features, edge_index, edge_types, out, csr, scratch)   # keep buffers alive
+        keep = (node_features, edge_index, edge_types, out, scratch)   # keep buffers alive
 
         def step(stream_handle: int, _keep=keep) -> None:
-            status = build(p_ei, p_et, nodes, edges, p_rp, p_col, p_typ, p_ws, ws_bytes,
-                           stream_handle)
-            if status == 0:
-                status = encode(handle, p_x, p_rp, p_col, p_typ, nodes, edges, None, p_out,
-                                out_code, 1, p_ws, ws_bytes, stream_handle)
+            status = encode(handle, p_x, p_ei, p_et, nodes, edges, None, p_out, out_code, 1,
+                            p_ws, ws_bytes, stream_handle)
             if status != 0:
-                native.check(status, "gfy_build_csr / gfy_encode")
+                native.check(status, "gfy_encode_coo")
         return step
 
     def hidden(self, node_features: torch.Tensor, csr: DeviceCsr,
@@ -286,6 +318,5 @@ class DeviceEncoder:
         x = torch.from_numpy(np.ascontiguousarray(node_features)).to(self.device)
         ei = torch.from_numpy(np.ascontiguousarray(edge_index)).to(self.device)
         et = torch.from_numpy(np.ascontiguousarray(edge_types)).to(self.device)
-        csr = self.build_csr(ei, et, nodes)
-        return self.encode(x, csr, out_rows=out_rows, n_out=n_out,
-                           out_dtype=out_dtype, normalise=normalise, out=out)
+        return self.encode_coo(x, ei, et, out_rows=out_rows, n_out=n_out,
+                               out_dtype=out_dtype, normalise=normalise, out=out)

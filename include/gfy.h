@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GFY_ABI_VERSION 1
+#define GFY_ABI_VERSION 2
 
 enum gfy_status {
   GFY_OK = 0,
@@ -144,6 +144,27 @@ int gfy_encode(gfy_encoder* encoder, const float* node_features,
                int64_t n_nodes, int64_t n_edges, const int32_t* out_rows,
                void* out, int out_dtype, int normalise, void* workspace,
                size_t workspace_bytes, void* stream);
+
+/* The whole seam in one call: COO in, embeddings out — Ginfinity._run_graph_shard
+ * (api.py:236-252) for one micro-batch.  Same result as gfy_build_csr + gfy_encode with fewer
+ * launches: the last stage of the CSR build runs inside the encoder's setup launch and no
+ * counter is zeroed per call (3 + layers launches instead of 6 + layers for the fp16 model).
+ *   edge_index / edge_types   as for gfy_build_csr; the other arguments as for gfy_encode
+ *   workspace                 gfy_encode_coo_workspace_bytes(); its first
+ *                             gfy_encode_coo_clear_bytes(n_nodes) bytes must be ZERO when the
+ *                             call starts and are zero again when it has run: clear a new
+ *                             workspace once with gfy_encode_coo_prepare (or hipMemset the
+ *                             whole of it) and again whenever n_nodes / n_edges change or
+ *                             anything else has written to it.                             */
+size_t gfy_encode_coo_workspace_bytes(const gfy_encoder* encoder, int64_t n_nodes,
+                                      int64_t n_edges);
+size_t gfy_encode_coo_clear_bytes(int64_t n_nodes);
+int gfy_encode_coo_prepare(void* workspace, size_t workspace_bytes, int64_t n_nodes,
+                           void* stream);
+int gfy_encode_coo(gfy_encoder* encoder, const float* node_features,
+                   const int32_t* edge_index, const uint8_t* edge_types, int64_t n_nodes,
+                   int64_t n_edges, const int32_t* out_rows, void* out, int out_dtype,
+                   int normalise, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Debug/parity tap: copy the hidden state after `stage` into `out`
  * ([N][hidden] in the model dtype): stage 0 = input Linear, l+1 = after layer l.

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import numpy as np
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 
@@ -613,3 +614,67 @@ def test_context_rows_are_dropped_the_same_way_in_every_micro_batch(gpu_encoder,
     via_records = gpu_encoder.encode_many(windows, keep_paired_neighbours=True, context_hops=2)
     for a, b in zip(via_records, whole):
         assert a.tobytes() == b.tobytes()
+
+
+# ---- gfy_encode_coo: CSR build fused into the encoder's setup --------------------------------
+
+def test_encode_coo_equals_build_csr_then_encode(gpu_encoder, rouskin_shard):
+    """One call, three launches in front of the layers instead of six: same bytes as
+    gfy_build_csr + gfy_encode, for RNA micro-batches, hub / dense interchange shards (the
+    overflow path of csr_finish.inc), context rows, and a sequence of growing and shrinking
+    sizes on ONE workspace (its counters must be zero again after every call)."""
+    from ginfinity_amd import synthetic
+    engine = gpu_encoder._engine
+    shards = [rouskin_shard.slice(0, 40), _hub_shard(5), rouskin_shard.slice(40, 400),
+              synthetic.arbitrary_shard(9, nodes=3_001, edges=40_000),   # mean in-degree 13
+              rouskin_shard.slice(400, 410), synthetic.roofline_shard(1, records=2, length=1500),
+              rouskin_shard.slice(0, 413)]
+    for round_ in range(2):
+        for shard in shards:
+            x, ei, et = _device_inputs(gpu_encoder, shard)
+            rows = None
+            kept = shard.node_count
+            if shard.node_roles.any():
+                core = shard.node_roles == 0
+                kept = int(core.sum())
+                order = np.cumsum(core, dtype=np.int32) - np.int32(1)
+                order[~core] = -1
+                rows = torch.from_numpy(order).to(x.device)
+            csr = engine.build_csr(ei, et, shard.node_count)
+            want = engine.encode(x, csr, out_rows=rows, n_out=kept).cpu().numpy()
+            got = engine.encode_coo(x, ei, et, out_rows=rows, n_out=kept).cpu().numpy()
+            np.testing.assert_array_equal(got.view(np.uint16), want.view(np.uint16))
+    # fp32 / fp64 output goes through the stand-alone head behind the same entry point
+    shard = shards[0]
+    x, ei, et = _device_inputs(gpu_encoder, shard)
+    csr = engine.build_csr(ei, et, shard.node_count)
+    for dtype in (torch.float32, torch.float64):
+        want = engine.encode(x, csr, out_dtype=dtype).cpu().numpy()
+        got = engine.encode_coo(x, ei, et, out_dtype=dtype).cpu().numpy()
+        np.testing.assert_array_equal(got, want)
+
+
+def test_encode_coo_full_precision_model(gpu_encoder_fp32, rouskin_shard):
+    engine = gpu_encoder_fp32._engine
+    shard = rouskin_shard.slice(0, 16)
+    x, ei, et = _device_inputs(gpu_encoder_fp32, shard)
+    csr = engine.build_csr(ei, et, shard.node_count)
+    want = engine.encode(x, csr, out_dtype=torch.float32).cpu().numpy()
+    got = engine.encode_coo(x, ei, et, out_dtype=torch.float32).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+
+
+def test_edge_across_micro_batches_is_refused_like_the_reference(gpu_encoder, rouskin_shard):
+    """an edge from one graph into another passes the whole-shard range check; the
+    reference's per-slice GraphShard (graph.py:318-321 behind 414-444) raises, and so must the
+    micro-batch path here — before anything reaches the device."""
+    import dataclasses
+    from ginfinity_amd import GraphValidationError
+    shard = rouskin_shard.slice(0, 30)
+    edge_index = shard.edge_index.copy()
+    last_graph_first_node = int(shard.node_ptr[-2])
+    edge_index[0, 0] = last_graph_first_node            # source in the last graph, dst in the first
+    broken = dataclasses.replace(shard, edge_index=edge_index)
+    limit = int(max(shard.lengths)) + 10                 # forces several micro-batches
+    with pytest.raises(GraphValidationError, match="edge index outside shard node range"):
+        gpu_encoder.encode_graphs(broken, max_batch_nodes=limit)

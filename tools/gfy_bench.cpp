@@ -97,20 +97,29 @@ int main(int argc, char** argv) {
   CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
   CK(hipEventElapsedTime(&ms, e0, e1));
   printf("encode only: %.1f us/step\n", 1e3 * ms / steps);
+  // the whole seam as one call (gfy_encode_coo): 3 + 4 launches on a workspace cleared once
+  const size_t b3 = gfy_encode_coo_workspace_bytes(enc, N, E);
+  void* ws3; CK(hipMalloc(&ws3, b3)); CK(hipMemsetAsync(ws3, 0, b3, s));
+  for (int i = 0; i < 20; ++i)
+    GK(gfy_encode_coo(enc, dx, dei, det, N, E, nullptr, dout, GFY_F16, 1, ws3, b3, s));
+  CK(hipStreamSynchronize(s));
+  CK(hipEventRecord(e0, s));
+  for (int i = 0; i < steps; ++i)
+    GK(gfy_encode_coo(enc, dx, dei, det, N, E, nullptr, dout, GFY_F16, 1, ws3, b3, s));
+  CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  printf("gfy_encode_coo: %.1f us/step  -> %.1f M nodes/s\n", 1e3 * ms / steps, N * steps / ms / 1e3);
   const int max_lanes = getenv("GFY_BENCH_STREAMS") ? atoi(getenv("GFY_BENCH_STREAMS")) : 4;
   for (int lanes = 2; lanes <= max_lanes; lanes += lanes < 4 ? 1 : 2) {  // independent shards in flight on several streams
     std::vector<gfy_encoder*> encs(lanes); std::vector<hipStream_t> ss(lanes);
-    std::vector<int32_t*> rp(lanes), cl(lanes); std::vector<uint8_t*> ty(lanes);
-    std::vector<void*> outs(lanes), wa(lanes), wb(lanes);
+    std::vector<void*> outs(lanes), wb(lanes);
     for (int q = 0; q < lanes; ++q) {
       GK(gfy_encoder_create(pack.data(), bytes, GFY_F16, 0, &encs[q])); CK(hipStreamCreate(&ss[q]));
-      CK(hipMalloc(&rp[q], (N + 1) * 4)); CK(hipMalloc(&cl[q], E * 4)); CK(hipMalloc(&ty[q], E));
-      CK(hipMalloc(&outs[q], N * 128 * 2)); CK(hipMalloc(&wa[q], b1)); CK(hipMalloc(&wb[q], b2));
+      CK(hipMalloc(&outs[q], N * 128 * 2)); CK(hipMalloc(&wb[q], b3)); CK(hipMemset(wb[q], 0, b3));
     }
     auto step = [&](int i) {
       const int q = i % lanes;
-      GK(gfy_build_csr(dei, det, N, E, rp[q], cl[q], ty[q], wa[q], b1, ss[q]));
-      GK(gfy_encode(encs[q], dx, rp[q], cl[q], ty[q], N, E, nullptr, outs[q], GFY_F16, 1, wb[q], b2, ss[q]));
+      GK(gfy_encode_coo(encs[q], dx, dei, det, N, E, nullptr, outs[q], GFY_F16, 1, wb[q], b3, ss[q]));
     };
     for (int i = 0; i < 24; ++i) step(i);
     CK(hipDeviceSynchronize());
