@@ -79,6 +79,13 @@ def parse() -> argparse.Namespace:
                         help="rows of the all-pairs nearest leg (0 = skip it)")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--cpu-seconds", type=float, default=12.0)
+    parser.add_argument("--workload", choices=("encode", "cross-shard"), default="encode",
+                        help="cross-shard = BASELINE configs[4] in miniature: shard-parallel "
+                             "encode + chunked RCCL all-gather + cross-shard nearest")
+    parser.add_argument("--shards", type=int, default=16,
+                        help="cross-shard workload: synthetic 60k-node shards over all ranks")
+    parser.add_argument("--chunk-rows", type=int, default=1 << 20,
+                        help="cross-shard workload: rows per rank per all-gather chunk")
     parser.add_argument("--spawn", action="store_true",
                         help="go through the rank launcher even for --gpus 1 (world size 1 "
                              "under torch.distributed.run, RCCL group created)")
@@ -204,6 +211,65 @@ def distance_leg(rows: int, device) -> dict:
                          "kernel": "k_pairwise"}}
 
 
+def cross_shard(args, rank: int, local_rank: int, world: int, distributed: bool) -> None:
+    """BASELINE configs[4] at a size that fits the run: every rank encodes its shards (no
+    collective), the fp16 blocks are exchanged chunk by chunk (all_gather_into_tensor: RCCL
+    over xGMI) while the chunks already there are searched, every rank keeps the nearest
+    other row of ITS rows over all ranks' rows.  Parity unpinned."""
+    import torch.distributed as dist
+    from ginfinity_amd import Ginfinity, parallel, synthetic
+    device = torch.device("cuda", local_rank)
+    encoder = Ginfinity.load(f"cuda:{local_rank}")
+    owned = parallel.shard_assignment(args.shards, world, rank)
+    shards = {s: synthetic.roofline_shard(s) for s in owned}
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    def longest(seconds: float) -> float:
+        if not distributed:
+            return seconds
+        worst = torch.tensor([seconds], dtype=torch.float64, device=device)
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        return float(worst.item())
+
+    encoder.encode_graphs_device(next(iter(shards.values())) if shards else synthetic.roofline_shard(0))
+    fence()
+    t0 = time.perf_counter()
+    blocks = [encoder.encode_graphs_device(shards[s])[0] for s in owned]
+    block = (torch.cat(blocks) if blocks else
+             torch.empty((0, 128), dtype=torch.float16, device=device))
+    torch.cuda.synchronize(device)
+    encode_s = longest(time.perf_counter() - t0)
+    fence()
+    t1 = time.perf_counter()
+    values, indices, offsets = parallel.cross_shard_nearest(block, metric="cosine",
+                                                            chunk_rows=args.chunk_rows)
+    torch.cuda.synchronize(device)
+    search_s = longest(time.perf_counter() - t1)
+    total = offsets[-1]
+    if rank == 0:
+        gathered_bytes = total * 128 * 2 * max(world - 1, 0)      # received by all ranks
+        print(json.dumps({
+            "metric": "cross-shard nearest over sharded embeddings (BASELINE configs[4] in "
+                      "miniature)", "value": float(total) * total / search_s,
+            "unit": "pairs/s", "n_gpus": world, "higher_is_better": True, "scaling": "strong",
+            "dtype": "f16", "data": "synthetic", "vs_baseline": None,
+            "config": {"workload": f"{args.shards} synthetic 60k-node shards over {world} GPU(s): "
+                                   "shard-parallel encode, chunked all-gather, nearest other row "
+                                   "(cosine) of every row", "rows_total": total,
+                       "chunk_rows": args.chunk_rows,
+                       "rccl_ranks": dist.get_world_size() if distributed else 0},
+            "encode": {"seconds": encode_s, "nodes_per_s": total / encode_s,
+                       "note": "numpy shards in, device blocks out (PCIe inclusive)"},
+            "exchange_and_search": {"seconds": search_s,
+                                    "bytes_received_all_ranks": gathered_bytes,
+                                    "tflops": 2.0 * total * total * 128 / search_s / 1e12},
+            "sample": [float(values[0]), int(indices[0])] if values.numel() else None}))
+
+
 def main() -> None:
     args = parse()
     if args.gpus < 1:
@@ -224,6 +290,11 @@ def main() -> None:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
+    if args.workload == "cross-shard":
+        cross_shard(args, rank, local_rank, world, distributed)
+        if distributed:
+            dist.destroy_process_group()
+        return
 
     from ginfinity_amd import Ginfinity, synthetic
     # one encoder handle (weights + workspace) per stream: shards are independent, so
@@ -301,16 +372,20 @@ def main() -> None:
             plain = times[1:-2]
             return sum(plain) / len(plain)
 
-        # (1) the timed configuration: every lane busy, events (none between the plain layer
-        # launches) on each lane's own stream
+        # (1) the timed configuration: every lane busy.  With several streams in flight the
+        # span between two HIP events of one stream contains the other streams' kernels, so
+        # the layer launches time themselves on the device clock (first workgroup start ->
+        # last workgroup end, gfy_encoder_set_timing(3)): the duration rocprofv3 reports
         for e in engines:
-            e.set_timing(2)
+            e.set_timing(3)
         batches, samples = min(max(args.steps // lanes, 1), 16), []
         for batch in range(batches):
             for lane in range(lanes):
                 step(batch * lanes + lane)
             torch.cuda.synchronize(device)
-            samples += [plain_layer_ms(e.kernel_times_ms()) for e in engines]
+            for e in engines:
+                per_layer = e.kernel_times_ms()
+                samples += per_layer[:-1]            # the last launch carries the head
         for e in engines:
             e.set_timing(False)
         timed_ms = sum(samples) / len(samples)
@@ -336,10 +411,13 @@ def main() -> None:
         roofline = {
             "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "kernel": "k_gine_layer_f16", "algorithmic_bytes_per_launch": LAYER_BYTES,
-            "configuration": f"{lanes} shard(s) in flight on {lanes} stream(s), as timed",
+            "configuration": f"{lanes} shard(s) in flight on {lanes} stream(s), as timed; "
+                             "kernel_ms = device clock, first workgroup start to last end",
             **layer_roofline(timed_ms),
             "traffic": measured_traffic("k_gine_layer_f16"),
-            "isolated": {"configuration": "one shard at a time", **layer_roofline(plain_layer_ms(mean))},
+            "isolated": {"configuration": "one shard at a time, one HIP event pair around the "
+                                          "three plain layer launches",
+                         **layer_roofline(plain_layer_ms(mean))},
             "pipeline_frac": PIPELINE_BYTES * world * args.steps / elapsed / 1e9
                              / (HBM_PEAK_GBS * world),
         }

@@ -411,7 +411,11 @@ int gfy_encoder_set_timing(gfy_encoder* enc, int enable) {
     GFY_CHECK_HIP(hipSetDevice(enc->device));
     for (auto& ev : enc->events) GFY_CHECK_HIP(hipEventCreate(&ev));
   }
-  enc->timing = enable == 2 ? 2 : enable != 0;
+  if (enable == 3 && !enc->device_spans) {
+    GFY_CHECK_HIP(hipSetDevice(enc->device));
+    GFY_CHECK_HIP(hipMalloc((void**)&enc->device_spans, 2 * kMaxLayers * sizeof(unsigned long long)));
+  }
+  enc->timing = enable == 2 || enable == 3 ? enable : enable != 0;
   enc->events_recorded = 0;
   return GFY_OK;
 }
@@ -434,6 +438,20 @@ int gfy_encoder_set_option(gfy_encoder* enc, int option, int value) {
 int gfy_encoder_get_timing(gfy_encoder* enc, float* ms_host, int capacity, int* count) {
   clear_error();
   GFY_REQUIRE(enc && ms_host && count, GFY_ERR_INVALID, "gfy_encoder_get_timing: NULL argument");
+  if (enc->timing == 3) {   // device clock spans of the layer launches, 100 MHz
+    GFY_REQUIRE(capacity >= enc->layers, GFY_ERR_INVALID,
+                "gfy_encoder_get_timing: capacity %d < %d", capacity, enc->layers);
+    unsigned long long spans[2 * kMaxLayers];
+    GFY_CHECK_HIP(hipMemcpy(spans, enc->device_spans, sizeof spans, hipMemcpyDeviceToHost));
+    for (int l = 0; l < enc->layers; ++l) {
+      GFY_REQUIRE(spans[2 * l + 1] >= spans[2 * l], GFY_ERR_INVALID,
+                  "gfy_encoder_get_timing: layer launch %d left no span (no fp16 encode since "
+                  "timing was set to 3?)", l);
+      ms_host[l] = (float)((double)(spans[2 * l + 1] - spans[2 * l]) * 1e-5);   // 10 ns ticks
+    }
+    *count = enc->layers;
+    return GFY_OK;
+  }
   const int spans = enc->events_recorded - 1;
   GFY_REQUIRE(enc->timing && spans >= 1, GFY_ERR_INVALID,
               "gfy_encoder_get_timing: timing is off or nothing was recorded");
@@ -461,6 +479,7 @@ void gfy_encoder_destroy(gfy_encoder* enc) {
   for (auto& ev : enc->events)
     if (ev) (void)hipEventDestroy(ev);
   if (enc->device_blob) (void)hipFree(enc->device_blob);
+  if (enc->device_spans) (void)hipFree(enc->device_spans);
   delete enc;
 }
 

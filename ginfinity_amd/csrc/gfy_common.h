@@ -148,10 +148,14 @@ struct gfy_encoder {
   // rocprof's kernel durations do not contain.
   int separate_head = 0;      // GFY_OPT_SEPARATE_HEAD
   int timing = 0;
+  // timing == 3: every layer launch records the device clock (s_memrealtime, 100 MHz) of its
+  // first workgroup start and last workgroup end: the kernel's own duration, as a profiler
+  // sees it, also when other streams keep the chip busy between two events of this one
+  unsigned long long* device_spans = nullptr;   // [kMaxLayers][2] on the device
   hipEvent_t events[gfy::kMaxLayers + 3] = {};
   mutable int events_recorded = 0;
   void mark(hipStream_t s, int slot) const {
-    if (!timing) return;
+    if (!timing || timing == 3) return;
     if (timing == 2 && slot >= 2 && slot < layers) return;
     (void)hipEventRecord(events[slot], s);
     events_recorded = slot + 1;

@@ -501,6 +501,11 @@ static int encode_f16_on(const gfy_encoder* enc, const float* x, const int32_t* 
   enc->mark(s, 1);
   const int stop = tap_stage >= 0 ? tap_stage : enc->layers;
   if (const int rc = opt_in_layer_lds()) return rc;
+  if (enc->timing == 3) {   // start = +inf, end = 0 for every layer launch
+    static const unsigned long long init[2 * kMaxLayers] = {
+        ~0ull, 0, ~0ull, 0, ~0ull, 0, ~0ull, 0, ~0ull, 0, ~0ull, 0, ~0ull, 0, ~0ull, 0};
+    GFY_CHECK_HIP(hipMemcpyAsync(enc->device_spans, init, sizeof init, hipMemcpyHostToDevice, s));
+  }
   // fp16 output of a full encode: the last layer's launch runs the head as well
   // (GFY_OPT_SEPARATE_HEAD keeps the stand-alone head kernel: A/B runs and parity tests)
   const bool fuse_head =
@@ -511,7 +516,8 @@ static int encode_f16_on(const gfy_encoder* enc, const float* x, const int32_t* 
   k_gine_layer_f16<RES, HEAD><<<layer_grid, kLThreads, kLdsBytes, s>>>(                      \
       enc->f16.layer[l], ha, hb, row_ptr, col, typ, plans, (int)n, layer_tiles, enc->f16.head, \
       out_rows, (f16*)out, normalise,                                                        \
-      coo && l == 0 && csr_scan_free(n) ? coo->scratch.tile_sum : nullptr)
+      coo && l == 0 && csr_scan_free(n) ? coo->scratch.tile_sum : nullptr,                   \
+      enc->timing == 3 ? enc->device_spans + 2 * l : nullptr)
     if (enc->residual && with_head) GFY_LAUNCH_LAYER(true, true);
     else if (enc->residual) GFY_LAUNCH_LAYER(true, false);
     else if (with_head) GFY_LAUNCH_LAYER(false, true);

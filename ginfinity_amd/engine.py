@@ -280,7 +280,10 @@ class DeviceEncoder:
 
     def set_timing(self, enabled: bool | int) -> None:
         """True / 1: an event after every launch; 2: none between layer launches
-        1 .. L-1, whose mean is reported (agrees with rocprof's kernel durations)."""
+        1 .. L-1, whose mean is reported (agrees with rocprof's kernel durations for one
+        stream); 3: no events, the layer launches time themselves on the device clock —
+        ``kernel_times_ms`` then returns one duration per layer launch, valid with any number
+        of streams in flight."""
         native.check(self._lib.gfy_encoder_set_timing(
             self._handle, int(enabled)), "gfy_encoder_set_timing")
 

@@ -180,7 +180,11 @@ int gfy_encode_hidden(gfy_encoder* encoder, const float* node_features,
  * caller's stream (do not enable under graph capture).  enable = 2 leaves out the
  * events BETWEEN layer launches 1 .. layers-1 and reports their mean: an event between
  * two dependent kernels adds ~2.5 us of stream time that a profiler's kernel duration
- * does not contain.  gfy_encoder_get_timing
+ * does not contain.  enable = 3 (fp16 model) records no events: every layer launch notes the
+ * device clock of its first workgroup start and last workgroup end, and
+ * gfy_encoder_get_timing returns those `layers` kernel durations (10 ns resolution) — what a
+ * profiler reports, also when other streams' kernels run between two events of this stream.
+ * gfy_encoder_get_timing
  * waits for the last gfy_encode and writes milliseconds to ms_host:
  * [0] per-encode setup (tile plans + input Linear), [1..layers] GINE layer
  * launches, [layers+1] stand-alone head+normalise (fp16-model fp16 output: the

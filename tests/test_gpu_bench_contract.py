@@ -64,3 +64,13 @@ def test_bench_through_the_rank_launcher_world_size_one():
                 "--distance-rows", "0")
     assert line["n_gpus"] == 1 and line["config"]["rccl_ranks"] == 1
     assert line["value"] > 1e8 and line["cpu_baseline"] is None
+
+
+def test_cross_shard_workload_through_the_launcher():
+    """BASELINE configs[4] in miniature, one rank under torch.distributed.run (RCCL group
+    created): encode, chunked exchange + search, one JSON line."""
+    line = _run("--gpus", "1", "--spawn", "--workload", "cross-shard", "--shards", "2",
+                "--chunk-rows", "50000")
+    assert line["n_gpus"] == 1 and line["config"]["rccl_ranks"] == 1
+    assert line["config"]["rows_total"] == 120_000 and line["unit"] == "pairs/s"
+    assert line["encode"]["nodes_per_s"] > 1e6 and line["exchange_and_search"]["tflops"] > 1.0

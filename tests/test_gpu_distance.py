@@ -5,6 +5,7 @@ from __future__ import annotations
 
 import numpy as np
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 
@@ -108,11 +109,17 @@ def test_cross_shard_nearest_world_size_one(gpu_encoder):
     block, owned, counts = parallel.encode_owned_shards(gpu_encoder, shards)
     assert owned == [0, 1] and len(counts) == 2
     assert block.shape[0] == sum(sum(c) for c in counts)
-    values, indices, offsets = parallel.cross_shard_nearest(block, metric="cosine")
-    assert offsets == [0, block.shape[0]]
     ref_values, ref_indices = distance.nearest(block, metric="cosine", exclude_self=True)
-    np.testing.assert_array_equal(indices.cpu().numpy(), ref_indices.cpu().numpy())
-    np.testing.assert_array_equal(values.cpu().numpy(), ref_values.cpu().numpy())
+    # one chunk, and chunks that cut the block (the rows in front of / inside / behind the
+    # window of every chunk are searched separately and merged on the device)
+    for chunk_rows in (1 << 20, 1000, 257):
+        values, indices, offsets = parallel.cross_shard_nearest(block, metric="cosine",
+                                                                chunk_rows=chunk_rows)
+        assert offsets == [0, block.shape[0]] and indices.dtype == torch.int64
+        np.testing.assert_array_equal(indices.cpu().numpy(), ref_indices.cpu().numpy())
+        np.testing.assert_array_equal(values.cpu().numpy(), ref_values.cpu().numpy())
+    empty = parallel.cross_shard_nearest(block[:0], metric="l2")
+    assert empty[0].shape == (0,) and empty[1].shape == (0,) and empty[2] == [0, 0]
 
 
 @pytest.mark.parametrize("n,m", [(255, 129), (256, 128), (257, 385), (513, 640), (1, 513),
@@ -153,3 +160,40 @@ def test_nearest_duplicates_across_tiles_and_sweep_chunks():
     np.testing.assert_array_equal(idx.cpu().numpy(), 700 + np.arange(90))
     _, idx = distance.nearest(base, b, metric="cosine")
     np.testing.assert_array_equal(idx.cpu().numpy(), 700 + np.arange(90))
+
+
+@pytest.mark.parametrize("metric", ["l2", "cosine"])
+def test_config4_one_million_rows_sampled_against_the_float64_oracle(metric):
+    """BASELINE configs[3] at full size: nearest other row of each of 1,000,000 unit rows
+    (the 1M x 1M matrix is never materialised, 0.25 s).  4,096+ sampled a-rows — the rows on
+    both sides of every 256-row workgroup seam sampled, the first and the last rows, the
+    ragged last b-tile — are checked against the float64 definition (oracle.gine_numpy).
+    Parity unpinned: the reference has no implementation of this step."""
+    from oracle import gine_numpy as G
+    from ginfinity_amd import distance, synthetic
+    rows = 1_000_000
+    points = synthetic.unit_rows(0, rows)
+    device = torch.from_numpy(points).cuda()
+    values, indices = distance.nearest(device, metric=metric, exclude_self=True)
+    values, indices = values.cpu().numpy().astype(np.float64), indices.cpu().numpy()
+    assert values.shape == (rows,) and indices.min() >= 0 and indices.max() < rows
+    rng = np.random.default_rng(7)
+    seams = np.concatenate([np.array([256 * k - 1, 256 * k]) for k in rng.integers(1, rows // 256, 96)])
+    sample = np.unique(np.concatenate([
+        np.arange(0, 260), np.arange(rows - 600, rows), seams,
+        rng.integers(0, rows, 3_400)]))
+    assert sample.size >= 4_096
+    worst = 0.0
+    for start in range(0, sample.size, 512):            # 512 x 1M float64 block = 4 GB
+        block = sample[start:start + 512]
+        full = (G.pairwise_l2(points[block], points) if metric == "l2"
+                else G.pairwise_cosine(points[block], points))
+        full[np.arange(block.size), block] = np.inf if metric == "l2" else -np.inf   # self
+        best = full.min(axis=1) if metric == "l2" else full.max(axis=1)
+        picked = full[np.arange(block.size), indices[block]]
+        tolerance = 2e-6 if metric == "cosine" else 2e-5
+        assert not np.any(indices[block] == block)
+        np.testing.assert_allclose(picked, best, atol=tolerance)
+        np.testing.assert_allclose(values[block], picked, atol=tolerance)
+        worst = max(worst, float(np.abs(values[block] - best).max()))
+    print(f"config 4 ({metric}): {sample.size} sampled rows, max |value - oracle| = {worst:.2e}")

@@ -78,3 +78,77 @@ def test_shard_assignment_is_a_partition():
         assert seen == list(range(1024))
         loads = [len(parallel.shard_assignment(1024, size, r)) for r in range(size)]
         assert max(loads) - min(loads) <= 1
+
+
+# ---- chunked, overlapped cross-shard search (the collective + merge logic; the kernel behind
+# ---- `search` is covered by the single-GPU tests) ------------------------------------------
+
+def _oracle_search(a, b, *, metric="l2", exclude_offset=None):
+    """float64 definition (oracle/gine_numpy.py) with the library's signature: test stand-in
+    for distance.nearest on CPU tensors."""
+    from oracle import gine_numpy as G
+    an, bn = a.numpy(), b.numpy()
+    full = G.pairwise_l2(an, bn) if metric == "l2" else G.pairwise_cosine(an, bn)
+    if exclude_offset is not None and exclude_offset >= 0:
+        for i in range(an.shape[0]):
+            if i + exclude_offset < bn.shape[0]:
+                full[i, i + exclude_offset] = np.inf if metric == "l2" else -np.inf
+    index = full.argmin(axis=1) if metric == "l2" else full.argmax(axis=1)
+    value = full[np.arange(an.shape[0]), index] if an.shape[0] else np.zeros(0)
+    return (torch.from_numpy(value.astype(np.float32)), torch.from_numpy(index.astype(np.int32)))
+
+
+def _nearest_worker(rank: int, size: int, port: int, sizes: list[int], metric: str,
+                    chunk_rows: int, queue) -> None:
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    try:
+        block = _rows(rank, sizes[rank])
+        values, indices, offsets = parallel.cross_shard_nearest(
+            block, metric=metric, chunk_rows=chunk_rows, search=_oracle_search)
+        queue.put((rank, values.numpy(), indices.numpy(), offsets))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sizes,chunk_rows", [([7, 7], 3), ([5, 11], 4), ([0, 6], 4),
+                                              ([9, 0, 4], 5), ([3, 8, 5], 100)])
+@pytest.mark.parametrize("metric", ["l2", "cosine"])
+def test_cross_shard_nearest_chunked_gloo(sizes, chunk_rows, metric):
+    """Unequal and empty blocks, chunks smaller than / larger than the blocks, two and three
+    ranks: every rank's rows must find their nearest OTHER row among all ranks' rows."""
+    from oracle import gine_numpy as G
+    size = len(sizes)
+    context = mp.get_context("spawn")
+    queue = context.Queue()
+    port = _free_port()
+    procs = [context.Process(target=_nearest_worker,
+                             args=(r, size, port, sizes, metric, chunk_rows, queue))
+             for r in range(size)]
+    for p in procs:
+        p.start()
+    results = sorted((queue.get(timeout=180) for _ in procs), key=lambda item: item[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    everything = np.concatenate([_rows(r, sizes[r]).numpy() for r in range(size)])
+    full = G.pairwise_l2(everything, everything) if metric == "l2" else G.pairwise_cosine(everything, everything)
+    np.fill_diagonal(full, np.inf if metric == "l2" else -np.inf)
+    want = full.argmin(axis=1) if metric == "l2" else full.argmax(axis=1)
+    starts = np.concatenate(([0], np.cumsum(sizes)))
+    for rank, values, indices, offsets in results:
+        assert offsets == list(starts)
+        lo, hi = starts[rank], starts[rank + 1]
+        assert indices.shape == (hi - lo,) and indices.dtype == np.int64
+        np.testing.assert_array_equal(indices, want[lo:hi])
+        np.testing.assert_allclose(values, full[np.arange(lo, hi), want[lo:hi]], rtol=1e-6)
+
+
+def test_cross_shard_nearest_world_size_one_needs_no_process_group():
+    block = _rows(3, 13)
+    values, indices, offsets = parallel.cross_shard_nearest(
+        block, metric="cosine", chunk_rows=4, search=_oracle_search)
+    direct_v, direct_i = _oracle_search(block, block, metric="cosine", exclude_offset=0)
+    assert offsets == [0, 13]
+    np.testing.assert_array_equal(indices.numpy(), direct_i.numpy().astype(np.int64))
+    np.testing.assert_allclose(values.numpy(), direct_v.numpy())

@@ -10,9 +10,11 @@ import re
 import sys
 from pathlib import Path
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01c"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = Path(__file__).resolve().parent.parent
 src = root / "gpurun_out" / tag
+sys.path.insert(0, str(root))
+from bench import kernel_source_sha16  # noqa: E402  (bench.py reports `traffic` only while it matches)
 
 
 def short(name: str) -> str:
@@ -20,10 +22,8 @@ def short(name: str) -> str:
     if not m:
         return name[:40]
     base = m.group(1)
-    if base == "k_gine_layer_f16":          # <kResidual, kHead>
-        base += "<head>" if "ELb1EE" in name or "Lb1ELb1" in name and False else ""
-        if re.search(r"k_gine_layer_f16ILb[01]ELb1E", name):
-            base = "k_gine_layer_f16<+head>"
+    if base == "k_gine_layer_f16" and re.search(r"k_gine_layer_f16ILb[01]ELb1E", name):
+        base = "k_gine_layer_f16<+head>"          # <kResidual, kHead>
     return base
 
 
@@ -47,6 +47,7 @@ json.dump({
            "--kernel-trace only) -- ./tools/gfy_bench 60000 20 (tools/profile_round.sh); mean per "
            "dispatch; workload = 60,000-node / 300,000-edge synthetic shard",
     "units": "FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them",
+    "kernel_source_sha16": kernel_source_sha16(),
     "correction": "gfx950: FETCH_SIZE reports half the bytes of wide (16 B/lane) coalesced reads "
                   "(MI355X_MICROARCH.md, HBM section) -> hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024",
     "kernels": traffic}, open(root / "profiles" / f"{tag}_traffic_pmc.json", "w"), indent=1)
