@@ -134,7 +134,11 @@ class _Uploader:
         self._copied: list["torch.cuda.Event | None"] = [None] * slots
         self._next = 0
 
-    def __call__(self, arrays: Sequence[np.ndarray | None]) -> list[torch.Tensor | None]:
+    def __call__(self, arrays: Sequence) -> list[torch.Tensor | None]:
+        """``arrays``: numpy arrays, ``None``, or ``(array, scalar)`` = upload ``array - scalar``
+        (edge indices rebased to the micro-batch's first node, graph.py:414-444)."""
+        rebases = [item[1] if isinstance(item, tuple) else None for item in arrays]
+        arrays = [item[0] if isinstance(item, tuple) else item for item in arrays]
         offsets, total = [], 0
         for array in arrays:
             offsets.append(total)
@@ -149,10 +153,15 @@ class _Uploader:
             staging = self._staging[slot] = torch.empty(
                 max(total, 1 << 20), dtype=torch.uint8, pin_memory=True)
         host = staging.numpy()
-        for array, offset in zip(arrays, offsets):
+        for array, offset, rebase in zip(arrays, offsets, rebases):
             if array is not None and array.nbytes:
-                host[offset:offset + array.nbytes] = np.ascontiguousarray(array).reshape(
-                    -1).view(np.uint8)
+                # ONE pass from the source (a view of the shard — for a loaded shard a view of
+                # the file mapping) into pinned memory, rebasing on the way where asked
+                target = host[offset:offset + array.nbytes].view(array.dtype).reshape(array.shape)
+                if rebase is None:
+                    np.copyto(target, array)
+                else:
+                    np.subtract(array, rebase, out=target)
         on_device = torch.empty(max(total, 1), dtype=torch.uint8, device=self._device)
         on_device[:total].copy_(staging[:total], non_blocking=True)
         done = torch.cuda.Event()
@@ -380,7 +389,7 @@ class Ginfinity:
                 rows = np.cumsum(core, dtype=np.int32) - np.int32(1)
                 rows[~core] = -1
             features, edge_index, edge_types, out_rows = self._uploader(
-                (shard.node_features[n0:n1], shard.edge_index[:, e0:e1] - np.int32(n0),
+                (shard.node_features[n0:n1], (shard.edge_index[:, e0:e1], np.int32(n0)),
                  shard.edge_types[e0:e1], rows))
             block = self._engine.encode_coo(features, edge_index, edge_types,
                                             out_rows=out_rows, n_out=kept,

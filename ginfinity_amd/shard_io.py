@@ -16,8 +16,7 @@ from pathlib import Path
 from typing import Iterator, Literal
 
 import numpy as np
-from safetensors import safe_open
-from safetensors.numpy import load_file, save_file
+from safetensors.numpy import save_file
 
 from .spec import (GRAPH_SHARD_FORMAT, GRAPH_SHARD_FORMAT_VERSION,
                    NODE_ROLE_CORE, GraphCompatibilityError, GraphSpec,
@@ -34,6 +33,46 @@ def _sha256(path: Path) -> str:
         while chunk := handle.read(1 << 20):
             digest.update(chunk)
     return digest.hexdigest()
+
+
+_SAFETENSORS_DTYPES = {"F32": np.float32, "I32": np.int32, "I64": np.int64, "U8": np.uint8,
+                       "F16": np.float16, "F64": np.float64, "I8": np.int8, "I16": np.int16,
+                       "BOOL": np.bool_}
+
+
+def _map_tensors(path: Path) -> tuple[dict[str, str], dict[str, np.ndarray]]:
+    """(header metadata, {name: read-only array}) of a safetensors file WITHOUT reading it:
+    the arrays are views of one ``mmap`` of the file (8-byte little-endian header length, JSON
+    header with dtype / shape / data_offsets per tensor, then the byte buffer).  Pages come in
+    from the page cache when a micro-batch's slice is copied into the pinned upload buffer —
+    the only host copy between the file and the device (``safetensors.numpy.load_file`` reads
+    the whole payload into fresh arrays first)."""
+    size = path.stat().st_size
+    with path.open("rb") as handle:
+        prefix = handle.read(8)
+        if len(prefix) != 8:
+            raise ValueError("file too short for a safetensors header")
+        header_bytes = int.from_bytes(prefix, "little")
+        if header_bytes <= 0 or 8 + header_bytes > size:
+            raise ValueError("safetensors header length out of range")
+        header = json.loads(handle.read(header_bytes))
+    if not isinstance(header, dict):
+        raise ValueError("safetensors header is not an object")
+    metadata = header.pop("__metadata__", None) or {}
+    payload = np.memmap(path, mode="r", dtype=np.uint8, offset=8 + header_bytes,
+                        shape=(size - 8 - header_bytes,)) if size > 8 + header_bytes else \
+        np.zeros(0, np.uint8)
+    arrays = {}
+    for name, entry in header.items():
+        dtype = np.dtype(_SAFETENSORS_DTYPES[entry["dtype"]])
+        shape = tuple(int(d) for d in entry["shape"])
+        begin, end = (int(v) for v in entry["data_offsets"])
+        count = int(np.prod(shape, dtype=np.int64))
+        if not 0 <= begin <= end <= payload.shape[0] or end - begin != count * dtype.itemsize:
+            raise ValueError(f"tensor {name!r}: data offsets do not match dtype and shape")
+        arrays[name] = np.frombuffer(payload, dtype=dtype, count=count,
+                                     offset=begin).reshape(shape)
+    return metadata, arrays
 
 
 def graph_metadata_path(tensor_path: str | Path) -> Path:
@@ -158,13 +197,11 @@ def load_graph_shard(tensor_path: str | Path, *,
         if _sha256(tensor_path) != stored:
             raise GraphValidationError("graph shard checksum mismatch")
     try:
-        with safe_open(tensor_path, framework="np") as handle:
-            header = handle.metadata() or {}
+        header, arrays = _map_tensors(tensor_path)
         if (header.get("format") != GRAPH_SHARD_FORMAT
                 or header.get("format_version") != str(GRAPH_SHARD_FORMAT_VERSION)
                 or header.get("graph_spec_sha256") != spec.sha256):
             raise GraphValidationError("tensor header metadata mismatch")
-        arrays = load_file(tensor_path)
     except GraphValidationError:
         raise
     except Exception as error:

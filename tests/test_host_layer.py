@@ -379,3 +379,32 @@ def test_parallel_npz_writer_is_read_back_like_savez_compressed(tmp_path):
     big = write_npz(tmp_path / "many.npz", (f"m{i}" for i in range(66000)), many)
     with np.load(big) as back:
         assert len(back.files) == 66000 and float(back["m65999"][0]) == 65999.0
+
+
+def test_loaded_shard_arrays_are_views_of_the_file_mapping(tmp_path):
+    """f3: load_graph_shard maps the safetensors payload instead of reading it — the arrays are
+    read-only views of one mmap (no host copy before the pinned upload buffer) and equal what
+    safetensors itself loads; a truncated or inconsistent header is refused."""
+    from safetensors.numpy import load_file
+    from ginfinity_amd import GraphBuilder, load_graph_shard, save_graph_shard
+    from ginfinity_amd.shard_io import _map_tensors
+    shard = GraphBuilder().build_shard(_records())
+    tensor_path, _ = save_graph_shard(shard, tmp_path / "views.safetensors")
+    loaded = load_graph_shard(tensor_path)
+    reference = load_file(str(tensor_path))
+    for name in sorted(reference):     # whole-molecule shards store no residue_index / node_roles
+        array = getattr(loaded, name)
+        np.testing.assert_array_equal(array, reference[name])
+        assert array.dtype == reference[name].dtype and not array.flags.writeable
+        base = array
+        while getattr(base, "base", None) is not None:
+            base = base.base
+        assert isinstance(base, (np.memmap, memoryview)) or type(base).__name__ == "mmap", type(base)
+    data = tensor_path.read_bytes()
+    broken = tmp_path / "broken.safetensors"
+    broken.write_bytes(data[:-5])                      # payload shorter than the offsets say
+    with pytest.raises(ValueError):
+        _map_tensors(broken)
+    broken.write_bytes((10 ** 9).to_bytes(8, "little") + data[8:])
+    with pytest.raises(ValueError):
+        _map_tensors(broken)
