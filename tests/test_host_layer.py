@@ -408,3 +408,36 @@ def test_loaded_shard_arrays_are_views_of_the_file_mapping(tmp_path):
     broken.write_bytes((10 ** 9).to_bytes(8, "little") + data[8:])
     with pytest.raises(ValueError):
         _map_tensors(broken)
+
+
+def test_whole_shard_window_extraction_equals_the_per_record_builder(rouskin_records):
+    """f2: sliced records (windows + crossing-pair partners + context hops) are cut out of the
+    whole shard in one pass; the arrays must equal from_graphs(build_many(records)) — the
+    reference's per-record construction (graph.py:608-695) — bit for bit, for every option."""
+    from ginfinity_amd import RNA, GraphBuilder, GraphShard
+    rng = np.random.default_rng(11)
+    records = []
+    for index, record in enumerate(rouskin_records[:120]):
+        length = record.length
+        if index % 3 == 0 or length < 12:
+            records.append(record)                                   # unsliced among the sliced
+            continue
+        start = int(rng.integers(0, length - 6))
+        end = int(rng.integers(start + 1, min(length, start + 1 + int(rng.integers(3, 90))) + 1))
+        records.append(RNA(record.identifier, record.sequence, record.structure,
+                           start=start, end=end))
+    records.append(RNA("stem", "GGGAAACCCUUUUGGG", "......(((....)))", start=9, end=16))
+    assert sum(r.sliced for r in records) > 60
+    for keep, hops in ((False, 1), (True, 1), (True, 2), (True, 3)):
+        builder = GraphBuilder(keep_paired_neighbours=keep, context_hops=hops)
+        want = GraphShard.from_graphs(builder.build_many(records))
+        got = builder.build_shard(records)
+        for name in ("node_features", "edge_index", "edge_types", "node_ptr", "edge_ptr",
+                     "residue_index", "node_roles"):
+            a, b = getattr(got, name), getattr(want, name)
+            assert a.dtype == b.dtype and a.shape == b.shape, (name, keep, hops)
+            np.testing.assert_array_equal(a, b, err_msg=f"{name} keep={keep} hops={hops}")
+        assert (got.identifiers, got.sequences, got.structures) == (
+            want.identifiers, want.sequences, want.structures)
+        if keep:
+            assert (got.node_roles != 0).any()
