@@ -1,45 +1,53 @@
 #!/bin/bash
 # Reproduce the committed measurement set of a round on a GPU box:
 #   python -m ginfinity_amd.build && python -m ginfinity_amd.build --stamps && bash tools/build_tools.sh
-#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/profile_round.sh r01c'
-# Writes gpurun_out/<tag>/…; the summaries judged are then copied into profiles/.
+#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/profile_round.sh r02'
+# Writes gpurun_out/<tag>/…; `python tools/pmc_summary.py <tag>` condenses the counter passes
+# and the summaries judged are then copied into profiles/ (see profiles/README.md).
 set -o pipefail
-TAG=${1:-r01c}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 
 # 1. bench lines (default = 4 shards in flight; one shard at a time)
-timeout -k 10 300 python3 $R/bench.py --steps 1000 --warmup 100 > $OUT/bench_line.json 2> $OUT/bench_line.err || exit 1
-timeout -k 10 200 python3 $R/bench.py --steps 1000 --warmup 100 --streams 1 --no-cpu-baseline > $OUT/bench_1stream_line.json 2>> $OUT/bench_line.err || exit 1
+timeout -k 10 400 python3 $R/bench.py --steps 1000 --warmup 100 > $OUT/bench_line.json 2> $OUT/bench_line.err || exit 1
+timeout -k 10 200 python3 $R/bench.py --steps 1000 --warmup 100 --streams 1 --no-cpu-baseline --distance-rows 0 > $OUT/bench_1stream_line.json 2>> $OUT/bench_line.err || exit 1
 
 # 2. per-kernel durations of the same command (kernel trace + stats only)
 for S in 1 4; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/kt$S -o kt --output-format csv -- \
-    python3 $R/bench.py --steps 1000 --warmup 100 --streams $S --no-cpu-baseline > $OUT/bench_${S}stream_line_profiled.json 2> $OUT/kt$S.err || exit 1
+    python3 $R/bench.py --steps 1000 --warmup 100 --streams $S --no-cpu-baseline --distance-rows 0 > $OUT/bench_${S}stream_line_profiled.json 2> $OUT/kt$S.err || exit 1
 done
 
 # 3. HBM traffic counters: separate passes, kernel trace only (MI355X_MICROARCH.md, HBM section)
 for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"; do
   N=$(echo $C | cut -d' ' -f1)
-  timeout -k 10 200 rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$N -o pmc --output-format csv -- \
+  GFY_BENCH_STREAMS=1 timeout -k 10 200 rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$N -o pmc --output-format csv -- \
     $R/tools/gfy_bench 60000 20 > $OUT/pmc_$N.log 2>&1 || exit 1
 done
 
 # 4. SQ counters of the layer kernel (two passes of 8)
-timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS \
+GFY_BENCH_STREAMS=1 timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS \
   --kernel-trace -d $OUT/sq_a -o sq --output-format csv -- $R/tools/gfy_bench 60000 20 > $OUT/sq_a.log 2>&1 || exit 1
-timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM SQ_INSTS_MFMA \
+GFY_BENCH_STREAMS=1 timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM SQ_INSTS_MFMA \
   --kernel-trace -d $OUT/sq_b -o sq --output-format csv -- $R/tools/gfy_bench 60000 20 > $OUT/sq_b.log 2>&1 || exit 1
 
 # 5. C++ driver (no Python in the loop) and in-kernel phase stamps (diagnostic build)
 timeout -k 10 100 $R/tools/gfy_bench 60000 200 > $OUT/gfy_bench.txt 2>&1 || exit 1
-timeout -k 10 100 $R/tools/gfy_bench_stamps 60000 50 > $OUT/gfy_bench_stamps.txt 2>&1 || exit 1
+GFY_BENCH_STREAMS=1 timeout -k 10 100 $R/tools/gfy_bench_stamps 60000 50 > $OUT/gfy_bench_stamps.txt 2>&1 || exit 1
 
-# 6. the other measured paths: all-pairs distance (config 4), API level incl. PCIe (config 2),
-#    and what a pure MFMA loop sustains on this part
-timeout -k 10 300 python3 $R/tools/bench_distance.py > $OUT/distance_bench.json 2> $OUT/distance.err || exit 1
+# 6. all-pairs distance (config 4): kernel durations and traffic of k_pairwise
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/kt_pairwise -o kt --output-format csv -- \
+  python3 $R/tools/bench_distance.py > $OUT/distance_bench.json 2> $OUT/distance.err || exit 1
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_pairwise_$C -o pmc --output-format csv -- \
+    python3 $R/tools/bench_distance.py --repeats 1 > $OUT/pmc_pairwise_$C.log 2>&1 || exit 1
+done
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT \
+  --kernel-trace -d $OUT/sq_pairwise -o sq --output-format csv -- python3 $R/tools/bench_distance.py --repeats 1 > $OUT/sq_pairwise.log 2>&1 || exit 1
+
+# 7. API level incl. PCIe (config 2) and shard file -> embeddings
 timeout -k 10 300 python3 $R/tools/bench_api.py > $OUT/api_bench.json 2> $OUT/api.err || exit 1
-timeout -k 10 100 $R/tools/mfma_peak > $OUT/mfma_peak.txt 2>&1 || exit 1
 echo done
