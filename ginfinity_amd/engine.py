@@ -8,6 +8,7 @@ streams and H2D/D2H copies only; every arithmetic step is a libgfy kernel.
 from __future__ import annotations
 
 import ctypes
+import warnings
 from dataclasses import dataclass
 
 import numpy as np
@@ -300,6 +301,12 @@ class DeviceEncoder:
         return [float(buffer[i]) for i in range(count.value)]
 
     # -- one micro-batch, host arrays in → device embeddings out ----------------------
+    def _upload(self, array: np.ndarray) -> torch.Tensor:
+        """Host array -> device tensor; read-only arrays (a memory-mapped shard) are only read."""
+        with warnings.catch_warnings():
+            warnings.filterwarnings("ignore", message="The given NumPy array is not writable")
+            return torch.from_numpy(np.ascontiguousarray(array)).to(self.device)
+
     def encode_arrays(self, node_features: np.ndarray, edge_index: np.ndarray,
                       edge_types: np.ndarray, node_roles: np.ndarray | None,
                       *, out_dtype: torch.dtype = torch.float16,
@@ -318,8 +325,6 @@ class DeviceEncoder:
                 rows = np.cumsum(core, dtype=np.int32) - np.int32(1)
                 rows[~core] = -1
                 out_rows = torch.from_numpy(rows).to(self.device)
-        x = torch.from_numpy(np.ascontiguousarray(node_features)).to(self.device)
-        ei = torch.from_numpy(np.ascontiguousarray(edge_index)).to(self.device)
-        et = torch.from_numpy(np.ascontiguousarray(edge_types)).to(self.device)
+        x, ei, et = (self._upload(a) for a in (node_features, edge_index, edge_types))
         return self.encode_coo(x, ei, et, out_rows=out_rows, n_out=n_out,
                                out_dtype=out_dtype, normalise=normalise, out=out)
