@@ -46,6 +46,8 @@ int main(int argc, char** argv) {
   }
   gfy_encoder* enc = nullptr;
   GK(gfy_encoder_create(pack.data(), bytes, GFY_F16, 0, &enc));
+  if (getenv("GFY_BENCH_SEPARATE_HEAD"))   // the last layer launch is then a plain one
+    GK(gfy_encoder_set_option(enc, GFY_OPT_SEPARATE_HEAD, 1));
   // graph: records of L nodes: backbone both ways, skip2 both ways, random matching both ways
   const int64_t recs = N / L;
   std::vector<int32_t> src, dst; std::vector<uint8_t> typ;
@@ -170,6 +172,21 @@ int main(int argc, char** argv) {
         ++used;
         b0 = real[b][0] < b0 ? real[b][0] : b0; b1 = real[b][0] > b1 ? real[b][0] : b1;
         e0 = real[b][1] < e0 ? real[b][1] : e0; e1 = real[b][1] > e1 ? real[b][1] : e1;
+      }
+      if (used && getenv("GFY_BENCH_WORKGROUPS")) {   // lifetimes per XCD, and the slowest few
+        double per_xcd[8] = {0}, worst_xcd[8] = {0}; int in_xcd[8] = {0};
+        for (int b = 0; b < 512; ++b) {
+          if (!real[b][1]) continue;
+          const double us = (real[b][1] - real[b][0]) / 100.0;
+          per_xcd[b & 7] += us; in_xcd[b & 7]++;
+          worst_xcd[b & 7] = us > worst_xcd[b & 7] ? us : worst_xcd[b & 7];
+        }
+        for (int x = 0; x < 8; ++x)
+          printf("  XCD %d: %d workgroups, lifetime mean %.2f us, longest %.2f us\n", x, in_xcd[x],
+                 per_xcd[x] / (in_xcd[x] ? in_xcd[x] : 1), worst_xcd[x]);
+        printf("  workgroup: start, end (us after the first start)\n");
+        for (int b = 0; b < 512; ++b)
+          if (real[b][1]) printf("  %3d %6.2f %6.2f\n", b, (real[b][0] - b0) / 100.0, (real[b][1] - b0) / 100.0);
       }
       if (used)
         printf("last layer launch, real time (100 MHz): %d workgroups, first start -> last start %.2f us, "
