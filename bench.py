@@ -22,9 +22,12 @@ synchronize, EXACTLY K timed steps, synchronize, MAX over ranks.
 
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   roofline      dominant kernel (k_gine_layer_f16): algorithmic bytes per launch
-                (512·N + 9·E + layer weights) ÷ its mean duration, measured
-                with HIP events on the launch streams IN THE TIMED CONFIGURATION (all
-                streams in flight); `isolated` repeats it one shard at a time; `traffic`
+                (512·N + 9·E + layer weights) ÷ its mean duration IN THE
+                TIMED CONFIGURATION (all streams in flight), taken on the device clock by
+                the launches themselves (first workgroup start -> last workgroup end,
+                gfy_encoder_set_timing(3): an event pair on one stream would include the
+                other streams' kernels); `isolated` repeats it one shard at a time with
+                HIP events around the launches; `traffic`
                 = HBM bytes per launch from the committed PMC passes, only while they
                 were taken from the kernel source as it is now (else null)
   distance      BASELINE configs[3]: all-pairs nearest over 1M x 128 fp16 rows, fraction
@@ -412,7 +415,12 @@ def main() -> None:
             "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "kernel": "k_gine_layer_f16", "algorithmic_bytes_per_launch": LAYER_BYTES,
             "configuration": f"{lanes} shard(s) in flight on {lanes} stream(s), as timed; "
-                             "kernel_ms = device clock, first workgroup start to last end",
+                             "kernel_ms = device clock, first workgroup start to last end "
+                             "(what rocprofv3 reports as the kernel's duration)",
+            "note": ("with several streams in flight the workgroups of different shards' "
+                     "kernels share the CUs, so a launch's span contains the others' work: "
+                     "`isolated` is the kernel by itself, `pipeline_frac` the whole step"
+                     if lanes > 1 else "one shard at a time: the span is the kernel by itself"),
             **layer_roofline(timed_ms),
             "traffic": measured_traffic("k_gine_layer_f16"),
             "isolated": {"configuration": "one shard at a time, one HIP event pair around the "
