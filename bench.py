@@ -393,24 +393,28 @@ def main() -> None:
             e.set_timing(False)
         timed_ms = sum(samples) / len(samples)
 
-        # (2) one shard at a time on torch's current stream, with the other kernels' times
+        # (2) one shard at a time: the same pre-bound gfy_encode_coo steps on lane 0 alone,
+        # an event pair around every kernel (timing mode 2; the count kernel of the CSR build
+        # runs in front of the first mark), then the whole step without the marks
         engine.set_timing(2)
         rounds = min(args.steps, 50)
         sums = None
-        csr_ms = 0.0
         for i in range(rounds):
-            x, ei, et = inputs[i % POOL]
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            csr = engine.build_csr(ei, et, NODES)
-            e1.record()
-            engine.encode(x, csr, out=outputs[i % POOL])
+            step(lanes * i)
+            torch.cuda.synchronize(device)
             times = engine.kernel_times_ms()
-            csr_ms += e0.elapsed_time(e1)
             sums = times if sums is None else [a + b for a, b in zip(sums, times)]
         engine.set_timing(False)
         mean = [t / rounds for t in sums]
+        with torch.cuda.stream(streams[0]):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(rounds):
+                step(lanes * i)
+            e1.record()
+        torch.cuda.synchronize(device)
+        alone_step_ms = e0.elapsed_time(e1) / rounds
         roofline = {
             "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "kernel": "k_gine_layer_f16", "algorithmic_bytes_per_launch": LAYER_BYTES,
@@ -429,8 +433,10 @@ def main() -> None:
             "pipeline_frac": PIPELINE_BYTES * world * args.steps / elapsed / 1e9
                              / (HBM_PEAK_GBS * world),
         }
-        kernels = {"configuration": "one shard at a time", "csr_build_ms": csr_ms / rounds,
-                   "setup_plans_input_linear_ms": mean[0], "layer_ms": mean[1:-2],
+        kernels = {"configuration": "one shard at a time on one stream (gfy_encode_coo: "
+                                    "k_csr_count, k_encode_setup_coo, 4 x k_gine_layer_f16)",
+                   "whole_step_ms": alone_step_ms,
+                   "csr_finish_plans_input_linear_ms": mean[0], "layer_ms": mean[1:-2],
                    "last_layer_with_head_normalise_ms": mean[-2]}
 
     distance = None
