@@ -63,6 +63,15 @@ json.dump({
            "dispatch, summed over the chip (SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count "
            "quad-cycles per wave, SQ_VALU_MFMA_BUSY_CYCLES and SQ_LDS_* count cycles)",
     "kernels": sq}, open(root / "profiles" / f"{tag}_layer_sq_pmc.json", "w"), indent=1)
+pairwise = src / "sq_pairwise" / "sq_counter_collection.csv"
+if pairwise.exists():
+    json.dump({
+        "how": "rocprofv3 --pmc (8 SQ counters, --kernel-trace only) -- python3 "
+               "tools/bench_distance.py --repeats 1: nearest other row of 1,000,000 x 128 fp16 "
+               "rows; mean per dispatch, summed over the chip; HBM traffic of the same launches "
+               "is in the traffic file",
+        "kernels": {k: v for k, v in means(pairwise).items() if k.startswith("k_")}},
+        open(root / "profiles" / f"{tag}_pairwise_sq_pmc.json", "w"), indent=1)
 for kernel in sorted(traffic):
     c = traffic[kernel]
     print(f"{kernel:28s} FETCH {c.get('FETCH_SIZE', 0):9.1f} KiB  WRITE {c.get('WRITE_SIZE', 0):9.1f} KiB  "
