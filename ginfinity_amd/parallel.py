@@ -7,11 +7,12 @@ MI355X node the same decomposition maps to ranks:
 * **encode is shard-parallel and needs no collective** — graphs never share
   edges across records (graph.py:392-395), weights (0.6 MB) are replicated,
   rank r encodes shards r, r+W, r+2W, …;
-* **the one exchange step** is the cross-shard nearest-neighbour search: every
-  rank all-gathers the fp16 embedding blocks (``all_gather_into_tensor`` —
-  RCCL over xGMI on GPUs, gloo on CPU tensors in the tests), then searches its
-  own rows against all rows with the (i, i + own offset) pair excluded.  Row
-  reductions stay on the rank that owns the row: no second collective.
+* **the one exchange step** is the cross-shard nearest-neighbour search: the fp16
+  embedding blocks are all-gathered in chunks (``all_gather_into_tensor`` per chunk into
+  one of two staging buffers — RCCL over xGMI on GPUs, gloo on CPU tensors in the tests)
+  and every chunk is searched against the rank's own rows while the next one is in
+  flight; per row the best (value, global row) is merged on the device.  Row reductions
+  stay on the rank that owns the row: no second collective.
 
 With world size 1 (or no process group) every function degenerates to the
 single-GPU path without touching ``torch.distributed``.
