@@ -12,7 +12,8 @@ module.  Differences a user can observe, all deliberate:
   ``allow_nondeterministic_cuda`` is accepted for compatibility but not
   required;
 * the per-record arrays returned by one call are views into one host block
-  (C-contiguous, independent rows) instead of separate allocations.
+  (C-contiguous, independent rows) instead of separate allocations, unless
+  ``encoder.independent_outputs = True``.
 """
 from __future__ import annotations
 
@@ -192,6 +193,11 @@ class Ginfinity:
         self._graph_spec = checkpoint.graph_spec
         self.device = device
         self.full_precision = full_precision
+        #: True: every returned per-record array owns its memory, as the reference's do
+        #: (api.py:253-260: one tensor per record); False (default): the arrays of one
+        #: micro-batch are row ranges of ONE host block (no per-record copy — keeping a single
+        #: record alive keeps its block alive)
+        self.independent_outputs = False
 
     @classmethod
     def load(cls, device: str = "cuda", *,
@@ -404,15 +410,17 @@ class Ginfinity:
             outputs.extend(job.result())
         return outputs
 
-    @staticmethod
-    def _splitter(core_counts, embedding_dtype: np.dtype, exact: bool):
-        """host block → the per-record arrays of one micro-batch (views of the block)."""
+    def _splitter(self, core_counts, embedding_dtype: np.dtype, exact: bool):
+        """host block → the per-record arrays of one micro-batch (views of the block, or
+        copies with ``independent_outputs``)."""
         cuts = np.cumsum(core_counts)[:-1]
+        independent = self.independent_outputs
 
         def finish(host: np.ndarray) -> list[np.ndarray]:
             if not exact:
                 host = host.astype(embedding_dtype)
-            return np.split(host, cuts, axis=0)
+            parts = np.split(host, cuts, axis=0)
+            return [part.copy() for part in parts] if independent else parts
         return finish
 
     # -- the seam (reference: api.py:232-260) -----------------------------------------
@@ -427,10 +435,7 @@ class Ginfinity:
                          ) -> list[np.ndarray]:
         torch_dtype, _code, exact = device_output_dtype(embedding_dtype)
         block = self._encode_shard_device(shard, torch_dtype).cpu().numpy()
-        if not exact:
-            block = block.astype(embedding_dtype)
-        cuts = np.cumsum(shard.core_counts)[:-1]
-        return np.split(block, cuts, axis=0)
+        return self._splitter(shard.core_counts, embedding_dtype, exact)(block)
 
     def encode_graphs_device(self, shard: GraphShard, *,
                              max_batch_nodes: int = 60_000,

@@ -289,6 +289,25 @@ def test_api_contract(gpu_encoder):
     assert gpu_encoder.embedding_dimension == 128
 
 
+def test_independent_outputs_own_their_memory(gpu_encoder, rouskin_shard):
+    """Default: the per-record arrays of one micro-batch are row ranges of one host block
+    (documented difference).  ``independent_outputs``: one allocation per record, as the
+    reference returns them (api.py:253-260); same bytes either way, in the one- and the
+    many-micro-batch path."""
+    shard = rouskin_shard.slice(0, 40)
+    shared = gpu_encoder.encode_graphs(shard)
+    assert all(out.base is not None for out in shared)
+    gpu_encoder.independent_outputs = True
+    try:
+        for limit in (60_000, 4_000):
+            own = gpu_encoder.encode_graphs(shard, max_batch_nodes=limit)
+            assert all(out.base is None and out.flags.owndata for out in own)
+            for a, b in zip(shared, own):
+                np.testing.assert_array_equal(a, b)
+    finally:
+        gpu_encoder.independent_outputs = False
+
+
 # ---- full_precision (fp32 model) ------------------------------------------------------------
 
 def test_fp32_model_example8(gpu_encoder_fp32, golden):
