@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <mutex>
+#include <utility>
 
 #include "../../include/gfy.h"
 
@@ -48,6 +49,7 @@ typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef f16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -162,7 +162,6 @@ int main(int argc, char** argv) {
       printf("layer kernel phases, shader cycles per launch (wave 0 of each workgroup, mean):\n");
       for (int k = 0; k < 9; ++k) printf("  %-30s %8.0f\n", names[k], sum[k] / all);
       printf("  %-30s %8.0f (last launch only)\n", names[9], sum[9] / headed);
-      printf("  GEMM1: time inside the four BatchNorm epilogues: wave 0 %.0f, wave 4 %.0f\n", sum[14] / all, sum[15] / all);
       printf("  whole wave: %.0f cycles (plain layer), %.0f (with head)\n", sum[10] / plain, sum[12] / headed);
       static unsigned long long real[512][2];
       gfy_debug_real(&real[0][0]);
