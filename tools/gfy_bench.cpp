@@ -157,11 +157,13 @@ int main(int argc, char** argv) {
     {
       const double plain = sum[11], headed = sum[13], all = plain + headed;
       const char* names[10] = {"plan + own rows (hop 1)", "far rows DMA + wait (hop 2)", "barrier 1",
-                               "gather", "W0 over own stage + barrier 2", "GEMM1 + BatchNorm",
-                               "W1 wait + barrier 3", "GEMM2", "LayerNorm + store", "head + normalise"};
+                               "gather", "[W0 | W1] over own stage + barrier 2",
+                               "update MLP (both products, one pipeline)", "", "", "LayerNorm + store",
+                               "head + normalise"};
       printf("layer kernel phases, shader cycles per launch (wave 0 of each workgroup, mean):\n");
-      for (int k = 0; k < 9; ++k) printf("  %-30s %8.0f\n", names[k], sum[k] / all);
-      printf("  %-30s %8.0f (last launch only)\n", names[9], sum[9] / headed);
+      for (int k = 0; k < 9; ++k)
+        if (names[k][0]) printf("  %-42s %8.0f\n", names[k], sum[k] / all);
+      printf("  %-42s %8.0f (last launch only)\n", names[9], sum[9] / headed);
       printf("  whole wave: %.0f cycles (plain layer), %.0f (with head)\n", sum[10] / plain, sum[12] / headed);
       static unsigned long long real[512][2];
       gfy_debug_real(&real[0][0]);
