@@ -41,7 +41,9 @@ __global__ __launch_bounds__(256) void k_csr_count(
     const int32_t* __restrict__ dst, int64_t e_count, int64_t n, int32_t* __restrict__ count,
     int32_t* __restrict__ table, int32_t* __restrict__ overflow,
     int32_t* __restrict__ overflow_count, int32_t* __restrict__ tile_sum, int tiles) {
-  __shared__ int s_bins[kTileSums ? kCsrLocalScanTiles : 1];
+  // one bin per tile of THIS shard (dynamic: 7.5 KB at 60,000 nodes — next to the 152 KB of a
+  // resident layer workgroup of another stream a static 16 KB would not fit on the CU)
+  extern __shared__ int s_bins[];
   if constexpr (kTileSums) {
     for (int i = threadIdx.x; i < tiles; i += 256) s_bins[i] = 0;
     __syncthreads();
@@ -264,9 +266,11 @@ int launch_csr_count_scan(const CsrScratch& w, int32_t* sums, const int32_t* edg
   const int32_t* dst = edge_index + e;
   const bool local = csr_scan_free(n);
   const int blocks = (int)((e + kCountEdgesPerBlock - 1) / kCountEdgesPerBlock);
-  if (e > 0 && local)
-    k_csr_count<true><<<blocks, 256, 0, s>>>(dst, e, n, w.count, w.table, w.overflow,
-                                             w.overflow_count, w.tile_sum, (int)finish_tiles(n));
+  if (e > 0 && local) {
+    const int bins = (int)finish_tiles(n);
+    k_csr_count<true><<<blocks, 256, (size_t)bins * sizeof(int), s>>>(
+        dst, e, n, w.count, w.table, w.overflow, w.overflow_count, w.tile_sum, bins);
+  }
   else if (e > 0)
     k_csr_count<false><<<blocks, 256, 0, s>>>(dst, e, n, w.count, w.table, w.overflow,
                                               w.overflow_count, nullptr, 0);
