@@ -78,7 +78,7 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(dx, x.data(), N * 7 * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dei, ei.data(), 2 * E * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(det, typ.data(), E, hipMemcpyHostToDevice));
-  hipStream_t s; CK(hipStreamCreate(&s));
+  hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
   for (int i = 0; i < 20; ++i) {
     GK(gfy_build_csr(dei, det, N, E, drp, dcol, dtyp, ws1, b1, s));
@@ -116,7 +116,7 @@ int main(int argc, char** argv) {
     std::vector<gfy_encoder*> encs(lanes); std::vector<hipStream_t> ss(lanes);
     std::vector<void*> outs(lanes), wb(lanes);
     for (int q = 0; q < lanes; ++q) {
-      GK(gfy_encoder_create(pack.data(), bytes, GFY_F16, 0, &encs[q])); CK(hipStreamCreate(&ss[q]));
+      GK(gfy_encoder_create(pack.data(), bytes, GFY_F16, 0, &encs[q])); CK(hipStreamCreateWithFlags(&ss[q], hipStreamNonBlocking));
       CK(hipMalloc(&outs[q], N * 128 * 2)); CK(hipMalloc(&wb[q], b3)); CK(hipMemset(wb[q], 0, b3));
     }
     auto step = [&](int i) {
