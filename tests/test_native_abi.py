@@ -59,3 +59,21 @@ def test_argument_errors_without_a_gpu(checkpoint):
     assert lib.gfy_encode(None, None, None, None, None, 1, 0, None, None, 0, 1, None, 0,
                           None) == native.GFY_ERR_INVALID
     assert lib.gfy_csr_workspace_bytes(60_000, 300_000) > 2 * 4 * 300_000
+
+
+def test_layer_kernel_keeps_its_register_and_scratch_budget():
+    """The fused layer kernel must not spill: a scratch reload is a `vmcnt` wait that drains the
+    LDS-DMA look-ahead, and more than 256 VGPRs would halve the waves per SIMD (two per SIMD
+    is what one 512-thread workgroup per CU needs).  hipcc cross-compiles, no GPU needed."""
+    import subprocess
+    script = Path(__file__).resolve().parents[1] / "tools" / "kernel_resources.sh"
+    done = subprocess.run(["bash", str(script)], capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0, done.stderr[-2000:]
+    layers = [line for line in done.stdout.splitlines() if "k_gine_layer_f16" in line]
+    assert len(layers) == 4, done.stdout            # <kResidual, kHead> x 2 x 2
+    for line in layers:
+        fields = line.split()
+        vgprs = int(fields[fields.index("vgpr") + 1])
+        spilled = int(fields[fields.index("spilled") + 1])
+        scratch = int(fields[fields.index("scratch") + 1])
+        assert vgprs <= 256 and spilled == 0 and scratch == 0, line
