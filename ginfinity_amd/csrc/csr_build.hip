@@ -27,7 +27,6 @@ namespace {
 constexpr int kScanBlock = 256;
 constexpr int kScanItems = 8;  // per thread
 constexpr int kScanTile = kScanBlock * kScanItems;
-constexpr int kSmallRow = 32;
 constexpr int kDirectScanTiles = 64;   // up to here every scan block sums its own prefix
 
 constexpr int kCountEdgesPerBlock = 256;   // one per thread (1,024: 8.9 us, 256: 7.5 us at E = 300,000)
