@@ -158,11 +158,13 @@ int main(int argc, char** argv) {
       const double plain = sum[11], headed = sum[13], all = plain + headed;
       const char* names[10] = {"plan + own rows (hop 1)", "far rows DMA + wait (hop 2)", "barrier 1",
                                "gather", "[W0 | W1] over own stage + barrier 2",
-                               "update MLP (both products, one pipeline)", "", "", "LayerNorm + store",
-                               "head + normalise"};
-      printf("layer kernel phases, shader cycles per launch (wave 0 of each workgroup, mean):\n");
+                               "update MLP (both products, one pipeline)", "head: barrier 4 (image resident)", "head: both products", "LayerNorm + store",
+                               "head: normalise + store"};
+      printf("layer kernel phases, shader cycles per launch (one wave of each workgroup — wave 0 unless the\n"
+             "library was built with -DGFY_STAMP_WAVE=n —, mean):\n");
       for (int k = 0; k < 9; ++k)
-        if (names[k][0]) printf("  %-42s %8.0f\n", names[k], sum[k] / all);
+        if (k == 6 || k == 7) printf("  %-42s %8.0f (last launch only)\n", names[k], sum[k] / headed);
+        else printf("  %-42s %8.0f\n", names[k], sum[k] / all);
       printf("  %-42s %8.0f (last launch only)\n", names[9], sum[9] / headed);
       printf("  whole wave: %.0f cycles (plain layer), %.0f (with head)\n", sum[10] / plain, sum[12] / headed);
       static unsigned long long real[512][2];
