@@ -17,6 +17,7 @@ GFY_ERR_INVALID, GFY_ERR_UNSUPPORTED, GFY_ERR_HIP, GFY_ERR_WORKSPACE = 1, 2, 3, 
 GFY_F16, GFY_F32, GFY_F64 = 0, 1, 2
 GFY_L2, GFY_COSINE = 0, 1
 GFY_OPT_SEPARATE_HEAD = 2
+GFY_OPT_LAYER_KERNEL = 3
 ABI_VERSION = 2
 
 #: every symbol include/gfy.h declares: (restype, argtypes)

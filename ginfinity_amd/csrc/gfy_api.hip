@@ -98,6 +98,32 @@ struct Blob {
 
 inline f16 rh(float v) { return (f16)v; }  // RNE, as torch's .half()
 
+// Makes `device` current for the life of the guard and gives the caller's device back: the
+// library never leaves the calling thread on another device than it came with.
+struct DeviceGuard {
+  int previous = -1;
+  hipError_t status;
+  explicit DeviceGuard(int device) {
+    status = hipGetDevice(&previous);
+    if (status == hipSuccess && previous != device) status = hipSetDevice(device);
+  }
+  ~DeviceGuard() {
+    if (previous >= 0) (void)hipSetDevice(previous);
+  }
+};
+
+// Every launching entry point runs on the CALLER's current device (streams and buffers are the
+// caller's): an encoder built for another device is refused instead of faulting or silently
+// going through peer access.
+static int check_current_device(const gfy_encoder* enc, const char* who) {
+  int current = -1;
+  GFY_CHECK_HIP(hipGetDevice(&current));
+  GFY_REQUIRE(current == enc->device, GFY_ERR_INVALID,
+              "%s: the encoder lives on HIP device %d but the calling thread's current device is "
+              "%d (hipSetDevice / torch.cuda.device first)", who, enc->device, current);
+  return GFY_OK;
+}
+
 struct Reader {
   const float* p;
   const float* take(size_t n) {
@@ -154,7 +180,10 @@ int gfy_encoder_create(const void* weight_pack_host, size_t bytes,
                                     hd.out_dim));
   GFY_REQUIRE(model_dtype == GFY_F16 || model_dtype == GFY_F32, GFY_ERR_INVALID,
               "gfy_encoder_create: model_dtype must be GFY_F16 or GFY_F32");
-  GFY_CHECK_HIP(hipSetDevice(device));
+  DeviceGuard guard(device);   // the caller's current device is restored on every way out
+  GFY_CHECK_HIP(guard.status);
+  if (model_dtype == GFY_F16)
+    if (const int rc = prepare_device_f16()) return rc;
 
   const int H = kHidden, M = kMlp, L = (int)hd.layers, ED = (int)hd.edge_dim;
   Reader rd{reinterpret_cast<const float*>((const char*)weight_pack_host +
@@ -165,6 +194,12 @@ int gfy_encoder_create(const void* weight_pack_host, size_t bytes,
   enc->layers = L;
   enc->edge_dim = ED;
   enc->residual = (int)(hd.flags & 1u);
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess &&
+        cus >= 8)
+      enc->cus = cus & ~7;
+  }
 
   Blob blob;
   // offsets first (pointers are fixed up after the single upload)
@@ -407,13 +442,18 @@ int gfy_encoder_create(const void* weight_pack_host, size_t bytes,
 int gfy_encoder_set_timing(gfy_encoder* enc, int enable) {
   clear_error();
   GFY_REQUIRE(enc != nullptr, GFY_ERR_INVALID, "gfy_encoder_set_timing: encoder is NULL");
-  if (enable && !enc->events[0]) {
-    GFY_CHECK_HIP(hipSetDevice(enc->device));
+  GFY_REQUIRE(enable != 3 || enc->model_dtype == GFY_F16, GFY_ERR_UNSUPPORTED,
+              "gfy_encoder_set_timing: mode 3 (device-clock spans) exists for the fp16 model only");
+  DeviceGuard guard(enc->device);
+  GFY_CHECK_HIP(guard.status);
+  if (enable && !enc->events[0])
     for (auto& ev : enc->events) GFY_CHECK_HIP(hipEventCreate(&ev));
-  }
   if (enable == 3 && !enc->device_spans) {
-    GFY_CHECK_HIP(hipSetDevice(enc->device));
     GFY_CHECK_HIP(hipMalloc((void**)&enc->device_spans, 2 * kMaxLayers * sizeof(unsigned long long)));
+    // start = +inf, end = 0: a launch that never ran reads as "no span", not as garbage
+    unsigned long long init[2 * kMaxLayers];
+    for (int l = 0; l < kMaxLayers; ++l) init[2 * l] = ~0ull, init[2 * l + 1] = 0;
+    GFY_CHECK_HIP(hipMemcpy(enc->device_spans, init, sizeof init, hipMemcpyHostToDevice));
   }
   enc->timing = enable == 2 || enable == 3 ? enable : enable != 0;
   enc->events_recorded = 0;
@@ -429,6 +469,11 @@ int gfy_encoder_set_option(gfy_encoder* enc, int option, int value) {
                   "gfy_encoder_set_option: GFY_OPT_SEPARATE_HEAD must be 0 or 1 (got %d)", value);
       enc->separate_head = value;
       return GFY_OK;
+    case GFY_OPT_LAYER_KERNEL:
+      GFY_REQUIRE(value >= 0 && value <= 2, GFY_ERR_INVALID,
+                  "gfy_encoder_set_option: GFY_OPT_LAYER_KERNEL must be 0, 1 or 2 (got %d)", value);
+      enc->layer_kernel = value;
+      return GFY_OK;
     default:
       set_error("gfy_encoder_set_option: unknown option %d", option);
       return GFY_ERR_INVALID;
@@ -442,6 +487,9 @@ int gfy_encoder_get_timing(gfy_encoder* enc, float* ms_host, int capacity, int* 
     GFY_REQUIRE(capacity >= enc->layers, GFY_ERR_INVALID,
                 "gfy_encoder_get_timing: capacity %d < %d", capacity, enc->layers);
     unsigned long long spans[2 * kMaxLayers];
+    // the encode may have run on a non-blocking stream, which a plain hipMemcpy does not wait for
+    if (const int rc = check_current_device(enc, "gfy_encoder_get_timing")) return rc;
+    GFY_CHECK_HIP(hipStreamSynchronize(enc->last_stream));
     GFY_CHECK_HIP(hipMemcpy(spans, enc->device_spans, sizeof spans, hipMemcpyDeviceToHost));
     for (int l = 0; l < enc->layers; ++l) {
       GFY_REQUIRE(spans[2 * l + 1] >= spans[2 * l], GFY_ERR_INVALID,
@@ -546,6 +594,8 @@ static int encode_common(gfy_encoder* enc, const float* x, const int32_t* row_pt
               GFY_ERR_INVALID, "gfy_encode: unsupported out_dtype %d", out_dtype);
   GFY_REQUIRE(tap < 0 || tap <= enc->layers, GFY_ERR_INVALID,
               "gfy_encode_hidden: stage %d outside 0..%d", tap, enc->layers);
+  if (const int rc = check_current_device(enc, "gfy_encode")) return rc;
+  enc->last_stream = (hipStream_t)stream;
   if (enc->model_dtype == GFY_F16)
     return launch_encode_f16(enc, x, row_ptr, col, typ, n, e, out_rows, out,
                              out_dtype, normalise, tap, ws, ws_bytes,
@@ -592,6 +642,8 @@ int gfy_encode_coo(gfy_encoder* enc, const float* x, const int32_t* edge_index,
   const size_t need = gfy_encode_coo_workspace_bytes(enc, n, e);
   GFY_REQUIRE(ws_bytes >= need, GFY_ERR_WORKSPACE, "gfy_encode_coo: workspace %zu < required %zu",
               ws_bytes, need);
+  if (const int rc = check_current_device(enc, "gfy_encode_coo")) return rc;
+  enc->last_stream = (hipStream_t)stream;
   if (enc->model_dtype == GFY_F16)
     return launch_encode_coo_f16(enc, x, edge_index, edge_types, n, e, out_rows, out, out_dtype,
                                  normalise, ws, ws_bytes, (hipStream_t)stream);

@@ -149,11 +149,14 @@ struct gfy_encoder {
   // 1 .. layers-1: an event between two dependent kernels costs ~2.5 us of stream time that
   // rocprof's kernel durations do not contain.
   int separate_head = 0;      // GFY_OPT_SEPARATE_HEAD
+  int layer_kernel = 0;       // GFY_OPT_LAYER_KERNEL: 0 k_gine_layer_d, 1 round 2, 2 k_gine_layer_p
+  int cus = 256;              // compute units of the device (persistent grid)
   int timing = 0;
   // timing == 3: every layer launch records the device clock (s_memrealtime, 100 MHz) of its
   // first workgroup start and last workgroup end: the kernel's own duration, as a profiler
   // sees it, also when other streams keep the chip busy between two events of this one
   unsigned long long* device_spans = nullptr;   // [kMaxLayers][2] on the device
+  mutable hipStream_t last_stream = nullptr;    // stream of the last encode (get_timing waits on it)
   hipEvent_t events[gfy::kMaxLayers + 3] = {};
   mutable int events_recorded = 0;
   void mark(hipStream_t s, int slot) const {
@@ -197,6 +200,9 @@ int launch_build_graphs(const uint8_t* bases, const uint8_t* marks, const int64_
                         const float* positional, float* features, int32_t* edge_index,
                         uint8_t* edge_types, int32_t* first_invalid, hipStream_t s);
 
+// > 64 KB of dynamic LDS is an opt-in per kernel and per DEVICE: done once when an encoder is
+// created on a device, not per encode call
+int prepare_device_f16();
 int launch_encode_f16(const gfy_encoder* enc, const float* x,
                       const int32_t* row_ptr, const int32_t* col,
                       const uint8_t* typ, int64_t n, int64_t e,

@@ -95,6 +95,9 @@ __device__ __forceinline__ float row16_sum32(float v) {
 // into libgfy.so proper.
 __device__ unsigned long long g_stamps[256][16];
 __device__ unsigned long long g_real[512][2];   // last launch: 100 MHz begin / end per workgroup
+// experiment: the first 256 workgroups of a layer launch start (blockIdx / 8) * g_stagger shader
+// cycles late, so that the CUs of an XCD run their fill bursts at different times
+__device__ int g_stagger;
 #define STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
 #else
 #define STAMP(var)
@@ -388,6 +391,7 @@ __global__ __launch_bounds__(256) void k_copy_rows_f16(const f16* __restrict__ s
 
 #include "csr_finish.inc"
 #include "gine_layer.inc"
+#include "gine_layer_p.inc"
 
 int persistent_grid(int num_tiles) {
   int g = num_tiles < 256 ? num_tiles : 256;
@@ -400,6 +404,11 @@ int persistent_grid(int num_tiles) {
 #ifdef GFY_STAMPS
 extern "C" int gfy_debug_real(unsigned long long* host /*[512][2]*/) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_real), sizeof(g_real)) == hipSuccess
+             ? GFY_OK
+             : GFY_ERR_HIP;
+}
+extern "C" int gfy_debug_set_stagger(int cycles) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_stagger), &cycles, sizeof(cycles)) == hipSuccess
              ? GFY_OK
              : GFY_ERR_HIP;
 }
@@ -421,7 +430,8 @@ static size_t h_buffer_bytes(int64_t n) {
 }
 // ... plus one plan per 32-node tile (gine_layer.inc)
 static size_t plan_bytes(int64_t n) {
-  return align_up((size_t)((n + kLTile - 1) / kLTile) * kPlanBytes, 256);
+  const int64_t tiles = (n + kLTile - 1) / kLTile;   // staged plans, then the global slot words
+  return align_up(global_words_offset((int)tiles) + (size_t)tiles * kGlobalWordsBytes, 256);
 }
 size_t encode_f16_workspace_bytes(int64_t n, int64_t /*e*/) {
   return 2 * h_buffer_bytes(n) + plan_bytes(n);
@@ -430,7 +440,7 @@ size_t encode_f16_workspace_bytes(int64_t n, int64_t /*e*/) {
 // > 64 KB of dynamic LDS needs an opt-in per kernel and per DEVICE (a process may drive
 // several GPUs, from several threads)
 static PerDeviceOnce g_layer_lds_opt_in;
-static int opt_in_layer_lds() {
+int prepare_device_f16() {   // gfy_encoder_create, with the encoder's device current
   return g_layer_lds_opt_in.run([]() -> int {
 #define GFY_OPT_IN(kernel)                                                                 \
   GFY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel),                \
@@ -439,6 +449,12 @@ static int opt_in_layer_lds() {
     GFY_OPT_IN((k_gine_layer_f16<false, false>));
     GFY_OPT_IN((k_gine_layer_f16<true, true>));
     GFY_OPT_IN((k_gine_layer_f16<false, true>));
+    GFY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gine_layer_p<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsBytes));
+    GFY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gine_layer_p<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsBytes));
+    GFY_OPT_IN((k_gine_layer_d<true>));
+    GFY_OPT_IN((k_gine_layer_d<false>));
 #undef GFY_OPT_IN
     return GFY_OK;
   });
@@ -500,7 +516,6 @@ static int encode_f16_on(const gfy_encoder* enc, const float* x, const int32_t* 
   }
   enc->mark(s, 1);
   const int stop = tap_stage >= 0 ? tap_stage : enc->layers;
-  if (const int rc = opt_in_layer_lds()) return rc;
   if (enc->timing == 3) {   // start = +inf, end = 0 for every layer launch
     static const unsigned long long init[2 * kMaxLayers] = {
         ~0ull, 0, ~0ull, 0, ~0ull, 0, ~0ull, 0, ~0ull, 0, ~0ull, 0, ~0ull, 0, ~0ull, 0};
@@ -508,9 +523,35 @@ static int encode_f16_on(const gfy_encoder* enc, const float* x, const int32_t* 
   }
   // fp16 output of a full encode: the last layer's launch runs the head as well
   // (GFY_OPT_SEPARATE_HEAD keeps the stand-alone head kernel: A/B runs and parity tests)
+  const bool persistent = enc->layer_kernel != 1;   // 0: eight free-running waves, 2: four
   const bool fuse_head =
-      tap_stage < 0 && out_dtype == GFY_F16 && stop > 0 && !enc->separate_head;
-  for (int l = 0; l < stop; ++l) {
+      tap_stage < 0 && out_dtype == GFY_F16 && stop > 0 && !enc->separate_head && !persistent;
+  // persistent kernel: one workgroup of four waves per CU, every wave walks its own tiles
+  const int tiles_per_xcd = (layer_tiles + 7) / 8;
+  const int waves = enc->layer_kernel == 2 ? kPWaves : kLWaves;
+  const int wanted = (tiles_per_xcd + waves - 1) / waves, per_xcd = enc->cus / 8;
+  const int p_grid = 8 * (wanted < per_xcd ? wanted : per_xcd);
+  for (int l = 0; l < stop && persistent; ++l) {
+    int32_t* const spent = coo && l == 0 && csr_scan_free(n) ? coo->scratch.tile_sum : nullptr;
+    unsigned long long* const span = enc->timing == 3 ? enc->device_spans + 2 * l : nullptr;
+    if (enc->layer_kernel == 0 && enc->residual)
+      k_gine_layer_d<true><<<p_grid, kLThreads, kLdsBytes, s>>>(
+          enc->f16.layer[l], ha, hb, row_ptr, col, typ, plans, (int)n, layer_tiles, spent, span);
+    else if (enc->layer_kernel == 0)
+      k_gine_layer_d<false><<<p_grid, kLThreads, kLdsBytes, s>>>(
+          enc->f16.layer[l], ha, hb, row_ptr, col, typ, plans, (int)n, layer_tiles, spent, span);
+    else if (enc->residual)
+      k_gine_layer_p<true><<<p_grid, kPThreads, kPLdsBytes, s>>>(
+          enc->f16.layer[l], ha, hb, row_ptr, col, typ, plans, (int)n, layer_tiles, spent, span);
+    else
+      k_gine_layer_p<false><<<p_grid, kPThreads, kPLdsBytes, s>>>(
+          enc->f16.layer[l], ha, hb, row_ptr, col, typ, plans, (int)n, layer_tiles, spent, span);
+    f16* sw = ha;
+    ha = hb;
+    hb = sw;
+    enc->mark(s, 2 + l);
+  }
+  for (int l = 0; l < stop && !persistent; ++l) {
     const bool with_head = fuse_head && l == stop - 1;
 #define GFY_LAUNCH_LAYER(RES, HEAD)                                                          \
   k_gine_layer_f16<RES, HEAD><<<layer_grid, kLThreads, kLdsBytes, s>>>(                      \

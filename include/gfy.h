@@ -197,7 +197,7 @@ int gfy_encoder_get_timing(gfy_encoder* encoder, float* ms_host, int capacity,
 /* Diagnostic options of one encoder (no reference counterpart; results within the stated
  * tolerances for every setting).  Set between encodes, never read from the environment.
  *   GFY_OPT_SEPARATE_HEAD  1: head + normalise as its own launch even for fp16 output      */
-enum gfy_option { GFY_OPT_SEPARATE_HEAD = 2 };
+enum gfy_option { GFY_OPT_SEPARATE_HEAD = 2, GFY_OPT_LAYER_KERNEL = 3 };
 int gfy_encoder_set_option(gfy_encoder* encoder, int option, int value);
 
 /* ---- all-pairs distance over 128-d embeddings ----------------------------------
