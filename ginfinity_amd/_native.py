@@ -6,7 +6,7 @@ caller gets an exception.  The product never routes around the kernels.
 from __future__ import annotations
 
 import ctypes
-from ctypes import (POINTER, c_char_p, c_int, c_int32, c_int64, c_size_t,
+from ctypes import (POINTER, Structure, c_char_p, c_int, c_int32, c_int64, c_size_t,
                     c_uint32, c_void_p)
 from pathlib import Path
 
@@ -18,7 +18,17 @@ GFY_F16, GFY_F32, GFY_F64 = 0, 1, 2
 GFY_L2, GFY_COSINE = 0, 1
 GFY_OPT_SEPARATE_HEAD = 2
 GFY_OPT_LAYER_KERNEL = 3
-ABI_VERSION = 2
+GFY_OPT_STAGGER = 4
+GFY_MAX_BATCH_SHARDS = 16
+GFY_TAP_H, GFY_TAP_Z, GFY_TAP_V, GFY_TAP_W, GFY_TAP_Y = 0, 1, 2, 3, 4
+ABI_VERSION = 3
+
+class GfyShard(Structure):
+    """``gfy_shard`` of include/gfy.h: one shard of a batch (device pointers)."""
+    _fields_ = [("node_features", c_void_p), ("edge_index", c_void_p),
+                ("edge_types", c_void_p), ("out_rows", c_void_p), ("out", c_void_p),
+                ("n_nodes", c_int64), ("n_edges", c_int64)]
+
 
 #: every symbol include/gfy.h declares: (restype, argtypes)
 SIGNATURES: dict[str, tuple] = {
@@ -47,6 +57,17 @@ SIGNATURES: dict[str, tuple] = {
     "gfy_encode_coo": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t,
                                c_void_p]),
+    "gfy_encode_coo_batch_workspace_bytes": (c_size_t, [c_void_p, POINTER(GfyShard), c_int]),
+    "gfy_encode_coo_batch_clear_bytes": (c_size_t, [POINTER(GfyShard), c_int]),
+    "gfy_encode_coo_batch": (c_int, [c_void_p, POINTER(GfyShard), c_int, c_int, c_int,
+                                     c_void_p, c_size_t, c_void_p]),
+    "gfy_host_encoder_create": (c_int, [c_void_p, c_size_t, c_int, POINTER(c_void_p)]),
+    "gfy_host_encoder_destroy": (None, [c_void_p]),
+    "gfy_host_encode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                c_void_p, c_void_p, c_int, c_int, c_int]),
+    "gfy_debug_layer_workspace_bytes": (c_size_t, [c_void_p, c_int64, c_int64]),
+    "gfy_debug_layer": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_int64, c_int64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "gfy_encoder_set_timing": (c_int, [c_void_p, c_int]),
     "gfy_encoder_set_option": (c_int, [c_void_p, c_int, c_int]),
     "gfy_encoder_get_timing": (c_int, [c_void_p, c_void_p, c_int,

@@ -5,12 +5,14 @@ reference (src/ginfinity/api.py:53-260); the compute under
 ``_run_graph_shard`` is the HIP path of libgfy instead of a ``torch.nn``
 module.  Differences a user can observe, all deliberate:
 
-* the device is an AMD GPU: ``device`` must be ``"cuda"``/``"cuda:i"`` (the HIP
-  device under PyTorch-ROCm).  ``device="cpu"`` raises — this package has no
-  CPU compute path (the CPU restatement lives in ``oracle/`` for tests only);
-* the kernels are deterministic (no atomics in the float path), so
-  ``allow_nondeterministic_cuda`` is accepted for compatibility but not
-  required;
+* ``device="cuda"``/``"cuda:i"`` is the HIP device under PyTorch-ROCm, i.e. an
+  MI355X; it needs ``allow_nondeterministic_cuda=True`` exactly as the
+  reference's CUDA path does (api.py:69-76) although these kernels are
+  deterministic (no atomics in the float path);
+* ``device="cpu"`` (the default, as in the reference) runs the host
+  implementation inside libgfy (csrc/gine_host.cpp: the same rounding-point
+  model in plain C++) — for boxes without a GPU and small inputs; an encoder
+  loaded for ``"cuda"`` never routes there, and nothing comes from ``oracle/``;
 * the per-record arrays returned by one call are views into one host block
   (C-contiguous, independent rows) instead of separate allocations, unless
   ``encoder.independent_outputs = True``.
@@ -28,6 +30,7 @@ import numpy as np
 import torch
 
 from .engine import DeviceEncoder, device_output_dtype
+from .host import HostEncoder
 from .graph import Graph, GraphBuilder, GraphShard, shard_text
 from .records import RNA
 from .spec import (DATA_DIRECTORY, GraphCompatibilityError, GraphSpec,
@@ -182,9 +185,11 @@ class Ginfinity:
     """Loaded GINFINITY encoder, resident on one MI355X, ready for repeated
     inference."""
 
-    def __init__(self, engine: DeviceEncoder, checkpoint: LoadedCheckpoint,
-                 device: str, *, full_precision: bool) -> None:
+    def __init__(self, engine: "DeviceEncoder | None", checkpoint: LoadedCheckpoint,
+                 device: str, *, full_precision: bool,
+                 host: "HostEncoder | None" = None) -> None:
         self._engine = engine
+        self._host = host
         self._copier: _Downloader | None = None
         self._preparer: ThreadPoolExecutor | None = None
         self._uploader: _Uploader | None = None
@@ -200,20 +205,23 @@ class Ginfinity:
         self.independent_outputs = False
 
     @classmethod
-    def load(cls, device: str = "cuda", *,
+    def load(cls, device: str = "cpu", *,
              allow_nondeterministic_cuda: bool = False,
              model_dir: str | Path | None = None,
              full_precision: bool = False) -> "Ginfinity":
-        del allow_nondeterministic_cuda      # deterministic kernels: no ack needed
-        if device == "cpu":
-            raise ValueError(
-                "this build runs the encoder on an AMD GPU only: use "
-                "device='cuda' (or 'cuda:<index>'); there is no CPU compute path")
-        if not isinstance(device, str) or not device.startswith("cuda"):
+        """Same signature, defaults and device policy as the reference
+        (src/ginfinity/api.py:64-76)."""
+        if not isinstance(device, str) or (device != "cpu" and not device.startswith("cuda")):
             raise ValueError("device must be 'cpu' or a CUDA device")
-        if not torch.cuda.is_available():
-            raise ValueError("CUDA was requested but is unavailable")
+        if device.startswith("cuda"):
+            if not allow_nondeterministic_cuda:
+                raise ValueError("CUDA requires allow_nondeterministic_cuda=True")
+            if not torch.cuda.is_available():
+                raise ValueError("CUDA was requested but is unavailable")
         checkpoint = load_checkpoint(model_dir)
+        if device == "cpu":
+            host = HostEncoder(checkpoint.weight_pack, full_precision=full_precision)
+            return cls(None, checkpoint, device, full_precision=full_precision, host=host)
         engine = DeviceEncoder(checkpoint.weight_pack,
                                full_precision=full_precision,
                                device=torch.device(device))
@@ -253,7 +261,7 @@ class Ginfinity:
         records = list(records)
         if not records:
             return []
-        if not any(record.sliced for record in records):
+        if self._host is None and not any(record.sliced for record in records):
             return self._encode_records(records, max_batch_nodes, max_batch_edges,
                                         _embedding_dtype(embedding_dtype))
         shard = GraphBuilder(
@@ -362,6 +370,11 @@ class Ginfinity:
                                    max_batch_nodes, max_batch_edges)
         if len(bounds) == 1:
             return self._run_graph_shard(shard, embedding_dtype)
+        if self._host is not None:   # device="cpu": micro-batch after micro-batch, as api.py:211-230
+            outputs: list[np.ndarray] = []
+            for start, stop in bounds:
+                outputs.extend(self._run_graph_shard(shard.slice(start, stop), embedding_dtype))
+            return outputs
         # Several micro-batches: the copy of batch k back to the host (15 MB, the long pole:
         # the kernels take 0.15 ms) runs on a helper thread while this thread slices,
         # uploads and launches batch k+1 — PCIe is full duplex.  Compute stays on ONE
@@ -433,6 +446,11 @@ class Ginfinity:
 
     def _run_graph_shard(self, shard: GraphShard, embedding_dtype: np.dtype
                          ) -> list[np.ndarray]:
+        if self._host is not None:
+            block = self._host.encode_arrays(
+                shard.node_features, shard.edge_index, shard.edge_types, shard.node_roles,
+                embedding_dtype=embedding_dtype)
+            return self._splitter(shard.core_counts, embedding_dtype, True)(block)
         torch_dtype, _code, exact = device_output_dtype(embedding_dtype)
         block = self._encode_shard_device(shard, torch_dtype).cpu().numpy()
         return self._splitter(shard.core_counts, embedding_dtype, exact)(block)
@@ -445,6 +463,8 @@ class Ginfinity:
         device tensor ([total core nodes, 128]) plus the per-record row counts —
         the input format of ``ginfinity_amd.distance``; nothing returns to
         the host."""
+        if self._engine is None:
+            raise ValueError("encode_graphs_device needs a GPU encoder (device='cuda')")
         shard = self._checked_shard(shard, max_batch_nodes, max_batch_edges)
         pieces = [
             self._encode_shard_device(

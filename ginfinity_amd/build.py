@@ -17,16 +17,12 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIBRARY = CSRC / "libgfy.so"
 SOURCES = ("gfy_api.hip", "graph_build.hip", "csr_build.hip", "gine_f16.hip",
-           "gine_f32.hip", "pairwise.hip")
+           "gine_f32.hip", "pairwise.hip", "gine_host.cpp")
 ARCH = "gfx950"
 # -ffp-contract=off: the rounding-point contract needs mul and add to round
 # separately unless the source says fma.
-# -amdgpu-mfma-vgpr-form: MFMA results stay in ordinary VGPRs, where the vector epilogues read
-# them; the accumulation half of the register file then holds what the kernels pin there (the
-# W0 fragments of the persistent layer kernel, gine_layer_p.inc).
 FLAGS = ("-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}",
-         "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
-         "-mllvm", "-amdgpu-mfma-vgpr-form")
+         "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function")
 
 
 def _hipcc() -> str:

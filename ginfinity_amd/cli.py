@@ -1,7 +1,8 @@
 """Command-line interface — drop-in for ``ginfinity`` (reference:
 src/ginfinity/cli.py:226-305): ``info``, ``alignment-config``, ``embed``,
 ``build-graphs``, ``embed-graphs`` with the same flags, NPZ + manifest outputs
-and exit code 2 on any error.  ``--device`` defaults to ``cuda`` (the MI355X);
+and exit code 2 on any error.  ``--device`` defaults to ``cpu`` as in the reference
+(cli.py:231,239,265); ``--device cuda --allow-nondeterministic-cuda`` selects the MI355X.
 ``build-graphs`` and ``alignment-config`` are host-only and need no GPU.
 """
 from __future__ import annotations
@@ -174,7 +175,7 @@ def _table_options(parser: argparse.ArgumentParser) -> None:
 
 
 def _encoder_options(parser: argparse.ArgumentParser) -> None:
-    parser.add_argument("--device", default="cuda")
+    parser.add_argument("--device", default="cpu")
     parser.add_argument("--allow-nondeterministic-cuda", action="store_true")
     parser.add_argument("--full-precision", action="store_true",
                         help="run model inference in float32 instead of float16")
@@ -191,7 +192,7 @@ def _parser() -> argparse.ArgumentParser:
     parser.add_argument("--version", action="version", version=PACKAGE_VERSION)
     commands = parser.add_subparsers(dest="command", required=True)
     info = commands.add_parser("info", help="show verified model metadata")
-    info.add_argument("--device", default="cuda")
+    info.add_argument("--device", default="cpu")
     alignment = commands.add_parser(
         "alignment-config", help="export parameters for ginfinity-sw")
     alignment.add_argument("--output", type=Path)

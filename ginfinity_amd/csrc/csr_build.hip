@@ -37,33 +37,48 @@ constexpr int kCountEdgesPerBlock = 256;   // one per thread (1,024: 8.9 us, 256
 // counts its edges per tile in LDS first and adds the non-zero bins.
 template <bool kTileSums>
 __global__ __launch_bounds__(256) void k_csr_count(
-    const int32_t* __restrict__ dst, int64_t e_count, int64_t n, int32_t* __restrict__ count,
-    int32_t* __restrict__ table, int32_t* __restrict__ overflow,
-    int32_t* __restrict__ overflow_count, int32_t* __restrict__ tile_sum, int tiles) {
-  // one bin per tile of THIS shard (dynamic: 7.5 KB at 60,000 nodes — next to the 152 KB of a
-  // resident layer workgroup of another stream a static 16 KB would not fit on the CU)
+    const ShardTable shards, int32_t* __restrict__ count, int2* __restrict__ table,
+    int32_t* __restrict__ overflow, int32_t* __restrict__ overflow_count,
+    int32_t* __restrict__ tile_sum, int bins) {
+  // one bin per tile of THIS BLOCK'S shard (dynamic: 7.5 KB at 60,000 nodes — next to the 152 KB
+  // of a resident layer workgroup of another stream a static 16 KB would not fit on the CU)
   extern __shared__ int s_bins[];
+  const int shard = shards.shard_of_count_block(blockIdx.x);       // block-uniform
+  const int n = shards.nodes[shard], e_count = shards.edges[shard];
+  const int first_row = shards.tile_base[shard] * kCsrTileRows;
+  const int32_t* __restrict__ src = shards.edge_index[shard];
+  const int32_t* __restrict__ dst = src + e_count;
+  const uint8_t* __restrict__ types = shards.edge_types[shard];
   if constexpr (kTileSums) {
-    for (int i = threadIdx.x; i < tiles; i += 256) s_bins[i] = 0;
+    for (int i = threadIdx.x; i < bins; i += 256) s_bins[i] = 0;
     __syncthreads();
   }
-  const int64_t first = (int64_t)blockIdx.x * kCountEdgesPerBlock;
+  const int64_t first =
+      (int64_t)(blockIdx.x - shards.count_block_base[shard]) * kCountEdgesPerBlock;
 #pragma unroll
   for (int k = 0; k < kCountEdgesPerBlock / 256; ++k) {
     const int64_t e = first + k * 256 + threadIdx.x;
     if (e >= e_count) continue;
     const int32_t d = dst[e];
-    if ((uint32_t)d >= (uint64_t)n) continue;   // not an edge of this shard: not in any row
-    const int slot = atomicAdd(&count[d], 1);
-    if (slot < kCsrSlots) table[(size_t)d * kCsrSlots + slot] = (int32_t)e;
-    else overflow[atomicAdd(overflow_count, 1)] = (int32_t)e;
+    if ((uint32_t)d >= (uint32_t)n) continue;   // not an edge of this shard: not in any row
+    const int row = first_row + d;               // global numbering from here on
+    const int id = shards.edge_base[shard] + (int)e;
+    // the edge's source (global row) and type travel with its id: the finish stage then needs
+    // no second, scattered visit to the edge arrays (both are streamed here anyway)
+    const uint32_t from = (uint32_t)src[e];
+    const uint32_t packed = (from < (uint32_t)n ? (uint32_t)first_row + from : kCsrNoSource) |
+                            ((uint32_t)types[e] << 24);
+    const int slot = atomicAdd(&count[row], 1);
+    if (slot < kCsrSlots) table[(size_t)row * kCsrSlots + slot] = make_int2(id, (int)packed);
+    else overflow[atomicAdd(overflow_count, 1)] = id;
     if constexpr (kTileSums) atomicAdd(&s_bins[d / kCsrTileRows], 1);
   }
   if constexpr (kTileSums) {
     __syncthreads();
+    const int tiles = (n + kCsrTileRows - 1) / kCsrTileRows;
     for (int i = threadIdx.x; i < tiles; i += 256) {
       const int edges = s_bins[i];
-      if (edges) atomicAdd(&tile_sum[i], edges);
+      if (edges) atomicAdd(&tile_sum[shards.tile_base[shard] + i], edges);
     }
   }
 }
@@ -201,10 +216,9 @@ __global__ __launch_bounds__(256) void k_zero(int32_t* __restrict__ count, int64
 // stage 3 on its own (gfy_build_csr); the fused setup of gine_f16.hip has the same body
 template <bool kScanned>
 __global__ __launch_bounds__(256) void k_csr_finish(
-    const CsrScratch w, int32_t* __restrict__ row_ptr, const int32_t* __restrict__ src,
-    const int32_t* __restrict__ dst, const uint8_t* __restrict__ types, int n,
-    int32_t* __restrict__ col, uint8_t* __restrict__ typ) {
-  csr_finish_tile<kScanned>(w, row_ptr, src, dst, types, n, blockIdx.x, col, typ);
+    const CsrScratch w, const ShardTable shards, int32_t* __restrict__ row_ptr,
+    int32_t* __restrict__ col, uint8_t* __restrict__ typ, int row_limit) {
+  csr_finish_tile<kScanned>(w, shards, row_ptr, blockIdx.x, col, typ, row_limit);
   csr_finish_release(w, gridDim.x);
 }
 
@@ -236,7 +250,7 @@ CsrScratch carve_csr(void* base, int64_t n, int64_t e, int32_t** sums, size_t* b
   w.count = (int32_t*)take((size_t)(n + 1) * 4);
   w.overflow_count = (int32_t*)take(256);
   w.tile_sum = (int32_t*)take((size_t)finish_tiles(n) * 4);
-  w.table = (int32_t*)take((size_t)n * kCsrSlots * 4);
+  w.table = (int2*)take((size_t)n * kCsrSlots * sizeof(int2));
   w.overflow = (int32_t*)take((size_t)e * 4);
   w.perm = (int32_t*)take((size_t)e * 4);
   int32_t* scan_sums = (int32_t*)take((size_t)tiles * 4);
@@ -247,7 +261,7 @@ CsrScratch carve_csr(void* base, int64_t n, int64_t e, int32_t** sums, size_t* b
 
 size_t csr_workspace_bytes(int64_t n, int64_t e) {
   size_t bytes = 0;
-  carve_csr(nullptr, n, e, nullptr, &bytes);
+  carve_csr(nullptr, finish_tiles(n) * kCsrTileRows, e, nullptr, &bytes);
   return bytes;
 }
 
@@ -258,22 +272,45 @@ int launch_csr_clear(void* ws, int64_t n, hipStream_t s) {
   return GFY_OK;
 }
 
-// stages 1 and 2 (the counters must be zero).  Shards of up to 131,072 nodes need no scan
-// launch: the finish stage sums the per-tile edge counts in front of its tile itself.
-int launch_csr_count_scan(const CsrScratch& w, int32_t* sums, const int32_t* edge_index,
-                          int64_t n, int64_t e, int32_t* row_ptr, hipStream_t s) {
-  const int32_t* dst = edge_index + e;
-  const bool local = csr_scan_free(n);
-  const int blocks = (int)((e + kCountEdgesPerBlock - 1) / kCountEdgesPerBlock);
-  if (e > 0 && local) {
-    const int bins = (int)finish_tiles(n);
+ShardTable single_shard(const float* x, const int32_t* edge_index, const uint8_t* edge_types,
+                        int64_t n, int64_t e, const int32_t* out_rows, void* out) {
+  ShardTable t{};
+  t.shards = 1;
+  t.tile_base[1] = (int)finish_tiles(n);
+  t.edge_base[1] = (int)e;
+  t.count_block_base[1] = (int)((e + kCountEdgesPerBlock - 1) / kCountEdgesPerBlock);
+  t.nodes[0] = (int)n;
+  t.edges[0] = (int)e;
+  t.x[0] = x;
+  t.edge_index[0] = edge_index;
+  t.edge_types[0] = edge_types;
+  t.out_rows[0] = out_rows;
+  t.out[0] = out;
+  return t;
+}
+
+int64_t largest_shard_nodes(const ShardTable& shards) {
+  int64_t most = 1;
+  for (int s = 0; s < shards.shards; ++s) most = shards.nodes[s] > most ? shards.nodes[s] : most;
+  return most;
+}
+
+// stages 1 and 2 (the counters must be zero).  While every shard has at most 131,072 nodes no
+// scan launch is needed: the finish stage sums the per-tile edge counts in front of its tile
+// (within its shard) itself.
+int launch_csr_count_scan(const CsrScratch& w, int32_t* sums, const ShardTable& shards,
+                          bool scan_free, int32_t* row_ptr, int64_t n /* rows of row_ptr */,
+                          hipStream_t s) {
+  const int blocks = shards.count_block_base[shards.shards];
+  if (blocks > 0 && scan_free) {
+    const int bins = (int)finish_tiles(largest_shard_nodes(shards));
     k_csr_count<true><<<blocks, 256, (size_t)bins * sizeof(int), s>>>(
-        dst, e, n, w.count, w.table, w.overflow, w.overflow_count, w.tile_sum, bins);
-  }
-  else if (e > 0)
-    k_csr_count<false><<<blocks, 256, 0, s>>>(dst, e, n, w.count, w.table, w.overflow,
+        shards, w.count, w.table, w.overflow, w.overflow_count, w.tile_sum, bins);
+  } else if (blocks > 0) {
+    k_csr_count<false><<<blocks, 256, 0, s>>>(shards, w.count, w.table, w.overflow,
                                               w.overflow_count, nullptr, 0);
-  if (!local) {
+  }
+  if (!scan_free) {
     const int tiles = (int)((n + kScanTile - 1) / kScanTile);
     if (tiles <= kDirectScanTiles) {
       k_scan_final<<<tiles, kScanBlock, 0, s>>>(w.count, row_ptr, n, nullptr);
@@ -291,26 +328,28 @@ int launch_csr_count_scan(const CsrScratch& w, int32_t* sums, const int32_t* edg
 int launch_build_csr(const int32_t* edge_index, const uint8_t* edge_types,
                      int64_t n, int64_t e, int32_t* row_ptr, int32_t* col,
                      uint8_t* typ, void* ws, size_t ws_bytes, hipStream_t s) {
-  GFY_REQUIRE(n > 0 && n < INT32_MAX && e >= 0 && e < INT32_MAX, GFY_ERR_INVALID,
+  GFY_REQUIRE(n > 0 && n < INT32_MAX - 64 && e >= 0 && e < INT32_MAX, GFY_ERR_INVALID,
               "gfy_build_csr: node/edge counts must fit int32 (n=%lld e=%lld)",
               (long long)n, (long long)e);
+  const ShardTable shards = single_shard(nullptr, edge_index, edge_types, n, e, nullptr, nullptr);
+  const int64_t rows = shards.total_rows();   // n rounded up to whole 32-row tiles
   int32_t* sums = nullptr;
   size_t need = 0;
-  const CsrScratch w = carve_csr(ws, n, e, &sums, &need);
+  const CsrScratch w = carve_csr(ws, rows, e, &sums, &need);
   GFY_REQUIRE(ws_bytes >= need, GFY_ERR_WORKSPACE,
               "gfy_build_csr: workspace %zu < required %zu", ws_bytes, need);
   // this entry point takes any scratch memory, so it clears the counters itself: four
   // launches, three without a scan (gfy_encode_coo on a cleared workspace: two, stage 3 fused
-  // with the setup)
-  if (const int rc = launch_csr_clear(ws, n, s)) return rc;
-  if (const int rc = launch_csr_count_scan(w, sums, edge_index, n, e, row_ptr, s)) return rc;
-  const int tiles = (int)finish_tiles(n);
-  if (csr_scan_free(n))
-    k_csr_finish<false><<<tiles, 256, 0, s>>>(w, row_ptr, edge_index, edge_index + e, edge_types,
-                                              (int)n, col, typ);
+  // with the setup).  The caller's row_ptr has n + 1 entries: rows of the last tile beyond n
+  // are not written (csr_finish.inc).
+  if (const int rc = launch_csr_clear(ws, rows, s)) return rc;
+  const bool scan_free = csr_scan_free(n);
+  if (const int rc = launch_csr_count_scan(w, sums, shards, scan_free, row_ptr, n, s)) return rc;
+  const int tiles = shards.total_tiles();
+  if (scan_free)
+    k_csr_finish<false><<<tiles, 256, 0, s>>>(w, shards, row_ptr, col, typ, (int)n);
   else
-    k_csr_finish<true><<<tiles, 256, 0, s>>>(w, row_ptr, edge_index, edge_index + e, edge_types,
-                                             (int)n, col, typ);
+    k_csr_finish<true><<<tiles, 256, 0, s>>>(w, shards, row_ptr, col, typ, (int)n);
   GFY_CHECK_HIP(hipGetLastError());
   return GFY_OK;
 }

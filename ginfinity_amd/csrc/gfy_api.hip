@@ -470,9 +470,16 @@ int gfy_encoder_set_option(gfy_encoder* enc, int option, int value) {
       enc->separate_head = value;
       return GFY_OK;
     case GFY_OPT_LAYER_KERNEL:
-      GFY_REQUIRE(value >= 0 && value <= 2, GFY_ERR_INVALID,
-                  "gfy_encoder_set_option: GFY_OPT_LAYER_KERNEL must be 0, 1 or 2 (got %d)", value);
+      GFY_REQUIRE(value == -1 || value == 1 || value == 3, GFY_ERR_INVALID,
+                  "gfy_encoder_set_option: GFY_OPT_LAYER_KERNEL must be -1 (by rounds), 1 (round-2 "
+                  "kernel) or 3 (persistent rounds), got %d", value);
       enc->layer_kernel = value;
+      return GFY_OK;
+    case GFY_OPT_STAGGER:
+      GFY_REQUIRE(value >= -1 && value <= 100000, GFY_ERR_INVALID,
+                  "gfy_encoder_set_option: GFY_OPT_STAGGER must be -1 (default) or 0..100000 "
+                  "cycles (got %d)", value);
+      enc->stagger = value;
       return GFY_OK;
     default:
       set_error("gfy_encoder_set_option: unknown option %d", option);
@@ -605,25 +612,55 @@ static int encode_common(gfy_encoder* enc, const float* x, const int32_t* row_pt
                            (hipStream_t)stream);
 }
 
-size_t gfy_encode_coo_clear_bytes(int64_t n) { return csr_clear_bytes(n < 1 ? 1 : n); }
+static int64_t padded_rows(int64_t n) { return (n + 31) / 32 * 32; }   // whole 32-row tiles
 
-size_t gfy_encode_coo_workspace_bytes(const gfy_encoder* enc, int64_t n, int64_t e) {
-  if (!enc) return 0;
-  n = n < 1 ? 1 : n;
-  e = e < 0 ? 0 : e;
-  if (enc->model_dtype == GFY_F16) return encode_coo_f16_workspace_bytes(n, e);
-  // fp32 model: plain sequence (CSR build, then encode), CSR arrays in front
+size_t gfy_encode_coo_clear_bytes(int64_t n) { return csr_clear_bytes(padded_rows(n < 1 ? 1 : n)); }
+
+// fp32 model: plain sequence (CSR build, then encode), CSR arrays in front
+static size_t encode_coo_f32_workspace_bytes(int64_t n, int64_t e) {
   return align_up(csr_workspace_bytes(n, e), 256) + align_up((size_t)(n + 1) * 4, 256) +
          align_up((size_t)(e > 0 ? e : 1) * 4, 256) + align_up((size_t)(e > 0 ? e : 1), 256) +
          encode_f32_workspace_bytes(n, e);
 }
 
+size_t gfy_encode_coo_workspace_bytes(const gfy_encoder* enc, int64_t n, int64_t e) {
+  if (!enc) return 0;
+  n = n < 1 ? 1 : n;
+  e = e < 0 ? 0 : e;
+  if (enc->model_dtype == GFY_F16) return encode_coo_f16_workspace_bytes(padded_rows(n), e);
+  return encode_coo_f32_workspace_bytes(n, e);
+}
+
 int gfy_encode_coo_prepare(void* ws, size_t ws_bytes, int64_t n, void* stream) {
   clear_error();
-  GFY_REQUIRE(ws && n > 0 && n < INT32_MAX, GFY_ERR_INVALID, "gfy_encode_coo_prepare: bad arguments");
-  GFY_REQUIRE(ws_bytes >= csr_clear_bytes(n), GFY_ERR_WORKSPACE,
-              "gfy_encode_coo_prepare: workspace %zu < %zu", ws_bytes, csr_clear_bytes(n));
-  return launch_csr_clear(ws, n, (hipStream_t)stream);
+  GFY_REQUIRE(ws && n > 0 && n < INT32_MAX - 64, GFY_ERR_INVALID,
+              "gfy_encode_coo_prepare: bad arguments");
+  GFY_REQUIRE(ws_bytes >= csr_clear_bytes(padded_rows(n)), GFY_ERR_WORKSPACE,
+              "gfy_encode_coo_prepare: workspace %zu < %zu", ws_bytes,
+              csr_clear_bytes(padded_rows(n)));
+  return launch_csr_clear(ws, padded_rows(n), (hipStream_t)stream);
+}
+
+// fp32 model (parity path, MFMA-bound): CSR build and encode behind one entry point
+static int encode_coo_f32(gfy_encoder* enc, const float* x, const int32_t* edge_index,
+                          const uint8_t* edge_types, int64_t n, int64_t e,
+                          const int32_t* out_rows, void* out, int out_dtype, int normalise,
+                          void* ws, size_t ws_bytes, hipStream_t stream) {
+  char* at = (char*)ws;
+  void* csr_ws = at;
+  const size_t csr_bytes = align_up(csr_workspace_bytes(n, e), 256);
+  at += csr_bytes;
+  int32_t* row_ptr = (int32_t*)at;
+  at += align_up((size_t)(n + 1) * 4, 256);
+  int32_t* col = (int32_t*)at;
+  at += align_up((size_t)(e > 0 ? e : 1) * 4, 256);
+  uint8_t* typ = (uint8_t*)at;
+  at += align_up((size_t)(e > 0 ? e : 1), 256);
+  if (const int rc = launch_build_csr(edge_index, edge_types, n, e, row_ptr, col, typ, csr_ws,
+                                      csr_bytes, stream))
+    return rc;
+  return launch_encode_f32(enc, x, row_ptr, col, typ, n, e, out_rows, out, out_dtype, normalise,
+                           -1, at, ws_bytes - (size_t)(at - (char*)ws), stream);
 }
 
 int gfy_encode_coo(gfy_encoder* enc, const float* x, const int32_t* edge_index,
@@ -632,7 +669,7 @@ int gfy_encode_coo(gfy_encoder* enc, const float* x, const int32_t* edge_index,
                    void* stream) {
   clear_error();
   GFY_REQUIRE(enc != nullptr, GFY_ERR_INVALID, "gfy_encode_coo: encoder is NULL");
-  GFY_REQUIRE(n > 0 && n < INT32_MAX && e >= 0 && e < INT32_MAX, GFY_ERR_INVALID,
+  GFY_REQUIRE(n > 0 && n < INT32_MAX - 64 && e >= 0 && e < INT32_MAX, GFY_ERR_INVALID,
               "gfy_encode_coo: n=%lld e=%lld out of range", (long long)n, (long long)e);
   GFY_REQUIRE(x && out && ws, GFY_ERR_INVALID, "gfy_encode_coo: NULL argument");
   GFY_REQUIRE(e == 0 || (edge_index && edge_types), GFY_ERR_INVALID,
@@ -645,24 +682,96 @@ int gfy_encode_coo(gfy_encoder* enc, const float* x, const int32_t* edge_index,
   if (const int rc = check_current_device(enc, "gfy_encode_coo")) return rc;
   enc->last_stream = (hipStream_t)stream;
   if (enc->model_dtype == GFY_F16)
-    return launch_encode_coo_f16(enc, x, edge_index, edge_types, n, e, out_rows, out, out_dtype,
-                                 normalise, ws, ws_bytes, (hipStream_t)stream);
-  // fp32 model (parity path, MFMA-bound): the two calls behind one entry point
-  char* at = (char*)ws;
-  void* csr_ws = at;
-  const size_t csr_bytes = align_up(csr_workspace_bytes(n, e), 256);
-  at += csr_bytes;
-  int32_t* row_ptr = (int32_t*)at;
-  at += align_up((size_t)(n + 1) * 4, 256);
-  int32_t* col = (int32_t*)at;
-  at += align_up((size_t)(e > 0 ? e : 1) * 4, 256);
-  uint8_t* typ = (uint8_t*)at;
-  at += align_up((size_t)(e > 0 ? e : 1), 256);
-  if (const int rc = launch_build_csr(edge_index, edge_types, n, e, row_ptr, col, typ, csr_ws,
-                                      csr_bytes, (hipStream_t)stream))
-    return rc;
-  return launch_encode_f32(enc, x, row_ptr, col, typ, n, e, out_rows, out, out_dtype, normalise,
-                           -1, at, ws_bytes - (size_t)(at - (char*)ws), (hipStream_t)stream);
+    return launch_encode_coo_f16(enc, single_shard(x, edge_index, edge_types, n, e, out_rows, out),
+                                 out_dtype, normalise, ws, ws_bytes, (hipStream_t)stream);
+  return encode_coo_f32(enc, x, edge_index, edge_types, n, e, out_rows, out, out_dtype, normalise,
+                        ws, ws_bytes, (hipStream_t)stream);
+}
+
+// ---- a batch of shards in one sequence of launches ---------------------------------------
+static int batch_table(const gfy_shard* shards, int count, const char* who, ShardTable* table) {
+  GFY_REQUIRE(shards && count >= 1 && count <= GFY_MAX_BATCH_SHARDS, GFY_ERR_INVALID,
+              "%s: 1..%d shards per call (got %d)", who, GFY_MAX_BATCH_SHARDS, count);
+  ShardTable t{};
+  t.shards = count;
+  int64_t tiles = 0, edges = 0, blocks = 0;
+  for (int s = 0; s < count; ++s) {
+    const gfy_shard& one = shards[s];
+    GFY_REQUIRE(one.n_nodes > 0 && one.n_edges >= 0, GFY_ERR_INVALID,
+                "%s: shard %d has n=%lld e=%lld", who, s, (long long)one.n_nodes,
+                (long long)one.n_edges);
+    GFY_REQUIRE(one.node_features && one.out, GFY_ERR_INVALID, "%s: shard %d: NULL argument", who,
+                s);
+    GFY_REQUIRE(one.n_edges == 0 || (one.edge_index && one.edge_types), GFY_ERR_INVALID,
+                "%s: shard %d: NULL edge array with E=%lld", who, s, (long long)one.n_edges);
+    t.tile_base[s] = (int)tiles;
+    t.edge_base[s] = (int)edges;
+    t.count_block_base[s] = (int)blocks;
+    t.nodes[s] = (int)one.n_nodes;
+    t.edges[s] = (int)one.n_edges;
+    t.x[s] = one.node_features;
+    t.edge_index[s] = one.edge_index;
+    t.edge_types[s] = one.edge_types;
+    t.out_rows[s] = one.out_rows;
+    t.out[s] = one.out;
+    tiles += (one.n_nodes + 31) / 32;
+    edges += one.n_edges;
+    blocks += (one.n_edges + 255) / 256;
+    GFY_REQUIRE(tiles * 32 <= ((int64_t)1 << 24) && edges < INT32_MAX, GFY_ERR_UNSUPPORTED,
+                "%s: a batch holds at most 16,777,216 (padded) nodes and 2^31 - 1 edges", who);
+  }
+  t.tile_base[count] = (int)tiles;
+  t.edge_base[count] = (int)edges;
+  t.count_block_base[count] = (int)blocks;
+  *table = t;
+  return GFY_OK;
+}
+
+size_t gfy_encode_coo_batch_workspace_bytes(const gfy_encoder* enc, const gfy_shard* shards,
+                                            int count) {
+  clear_error();
+  ShardTable t;
+  if (!enc || batch_table(shards, count, "gfy_encode_coo_batch_workspace_bytes", &t)) return 0;
+  if (enc->model_dtype == GFY_F16)
+    return encode_coo_f16_workspace_bytes(t.total_rows(), t.total_edges());
+  size_t most = 0;   // fp32 model: the shards run one after the other in one workspace
+  for (int s = 0; s < count; ++s) {
+    const size_t one = encode_coo_f32_workspace_bytes(shards[s].n_nodes, shards[s].n_edges);
+    most = one > most ? one : most;
+  }
+  return most;
+}
+
+size_t gfy_encode_coo_batch_clear_bytes(const gfy_shard* shards, int count) {
+  clear_error();
+  ShardTable t;
+  if (batch_table(shards, count, "gfy_encode_coo_batch_clear_bytes", &t)) return 0;
+  return csr_clear_bytes(t.total_rows());
+}
+
+int gfy_encode_coo_batch(gfy_encoder* enc, const gfy_shard* shards, int count, int out_dtype,
+                         int normalise, void* ws, size_t ws_bytes, void* stream) {
+  clear_error();
+  GFY_REQUIRE(enc != nullptr && ws != nullptr, GFY_ERR_INVALID,
+              "gfy_encode_coo_batch: NULL encoder or workspace");
+  GFY_REQUIRE(out_dtype == GFY_F16 || out_dtype == GFY_F32 || out_dtype == GFY_F64,
+              GFY_ERR_INVALID, "gfy_encode_coo_batch: unsupported out_dtype %d", out_dtype);
+  ShardTable t;
+  if (const int rc = batch_table(shards, count, "gfy_encode_coo_batch", &t)) return rc;
+  const size_t need = gfy_encode_coo_batch_workspace_bytes(enc, shards, count);
+  GFY_REQUIRE(ws_bytes >= need, GFY_ERR_WORKSPACE,
+              "gfy_encode_coo_batch: workspace %zu < required %zu", ws_bytes, need);
+  if (const int rc = check_current_device(enc, "gfy_encode_coo_batch")) return rc;
+  enc->last_stream = (hipStream_t)stream;
+  if (enc->model_dtype == GFY_F16)
+    return launch_encode_coo_f16(enc, t, out_dtype, normalise, ws, ws_bytes, (hipStream_t)stream);
+  for (int s = 0; s < count; ++s)
+    if (const int rc = encode_coo_f32(enc, shards[s].node_features, shards[s].edge_index,
+                                      shards[s].edge_types, shards[s].n_nodes, shards[s].n_edges,
+                                      shards[s].out_rows, shards[s].out, out_dtype, normalise, ws,
+                                      ws_bytes, (hipStream_t)stream))
+      return rc;
+  return GFY_OK;
 }
 
 int gfy_encode(gfy_encoder* enc, const float* x, const int32_t* row_ptr,
@@ -681,6 +790,32 @@ int gfy_encode_hidden(gfy_encoder* enc, const float* x, const int32_t* row_ptr,
   return encode_common(enc, x, row_ptr, col, typ, n, e, nullptr, out,
                        enc ? enc->model_dtype : GFY_F16, 0, stage, ws, ws_bytes,
                        stream);
+}
+
+size_t gfy_debug_layer_workspace_bytes(const gfy_encoder* enc, int64_t n, int64_t /*e*/) {
+  if (!enc || enc->model_dtype != GFY_F16) return 0;
+  return debug_layer_f16_workspace_bytes(n < 1 ? 1 : n);
+}
+
+int gfy_debug_layer(gfy_encoder* enc, int layer, const void* hidden_in, const int32_t* row_ptr,
+                    const int32_t* col, const uint8_t* typ, int64_t n, int64_t e, int tap,
+                    void* out, void* ws, size_t ws_bytes, void* stream) {
+  clear_error();
+  GFY_REQUIRE(enc != nullptr, GFY_ERR_INVALID, "gfy_debug_layer: encoder is NULL");
+  GFY_REQUIRE(enc->model_dtype == GFY_F16, GFY_ERR_UNSUPPORTED,
+              "gfy_debug_layer: fp16 model only");
+  GFY_REQUIRE(layer >= 0 && layer < enc->layers, GFY_ERR_INVALID,
+              "gfy_debug_layer: layer %d outside 0..%d", layer, enc->layers - 1);
+  GFY_REQUIRE(tap >= GFY_TAP_H && tap <= GFY_TAP_Y, GFY_ERR_INVALID,
+              "gfy_debug_layer: unknown tap %d", tap);
+  GFY_REQUIRE(n > 0 && n < INT32_MAX - 64 && e >= 0 && e < INT32_MAX, GFY_ERR_INVALID,
+              "gfy_debug_layer: n=%lld e=%lld out of range", (long long)n, (long long)e);
+  GFY_REQUIRE(hidden_in && row_ptr && out && ws && (e == 0 || (col && typ)), GFY_ERR_INVALID,
+              "gfy_debug_layer: NULL argument");
+  if (const int rc = check_current_device(enc, "gfy_debug_layer")) return rc;
+  enc->last_stream = (hipStream_t)stream;
+  return launch_debug_layer_f16(enc, layer, hidden_in, row_ptr, col, typ, n, e, tap, out, ws,
+                                ws_bytes, (hipStream_t)stream);
 }
 
 int gfy_pairwise_dense(const void* a, int64_t n, const void* b, int64_t m,

@@ -149,8 +149,10 @@ struct gfy_encoder {
   // 1 .. layers-1: an event between two dependent kernels costs ~2.5 us of stream time that
   // rocprof's kernel durations do not contain.
   int separate_head = 0;      // GFY_OPT_SEPARATE_HEAD
-  int layer_kernel = 0;       // GFY_OPT_LAYER_KERNEL: 0 k_gine_layer_d, 1 round 2, 2 k_gine_layer_p
+  int layer_kernel = -1;      // GFY_OPT_LAYER_KERNEL: -1 by the launch's rounds, 1 round-2 kernel, 3 persistent rounds
   int cus = 256;              // compute units of the device (persistent grid)
+  int stagger = -1;           // GFY_OPT_STAGGER: start offset between the workgroups of an XCD in
+                              // shader cycles (persistent rounds); -1: 500 from three rounds up
   int timing = 0;
   // timing == 3: every layer launch records the device clock (s_memrealtime, 100 MHz) of its
   // first workgroup start and last workgroup end: the kernel's own duration, as a profiler
@@ -170,24 +172,71 @@ struct gfy_encoder {
 // ---- kernel launchers (one per .hip file) -------------------------------------------
 namespace gfy {
 
+// ---- a batch of shards in one sequence of launches ------------------------------------------
+// Shards never share edges (graph.py:392-395), so k of them are ONE graph for the kernels: shard
+// s owns the global rows [32 tile_base[s], 32 tile_base[s] + nodes[s]) — every shard starts on a
+// tile boundary, the rows between its last node and the next boundary are padding (isolated,
+// zero features, never stored to an output) — and the global edge ids [edge_base[s],
+// edge_base[s + 1]).  Hidden states, CSR and tile plans live in the workspace in global
+// numbering; only the kernels that touch the callers' arrays (edge list in, node features in,
+// embeddings out) look a tile's or an edge's shard up in this table, which travels as a kernel
+// argument.
+constexpr int kMaxBatchShards = 16;
+struct ShardTable {
+  int shards;
+  int tile_base[kMaxBatchShards + 1];         // [shards] = tiles of the batch
+  int edge_base[kMaxBatchShards + 1];         // [shards] = edges of the batch
+  int count_block_base[kMaxBatchShards + 1];  // blocks of the counting kernel, per shard
+  int nodes[kMaxBatchShards];
+  int edges[kMaxBatchShards];
+  const float* x[kMaxBatchShards];            // [nodes][in_dim]
+  const int32_t* edge_index[kMaxBatchShards]; // [2][edges], shard-local node ids
+  const uint8_t* edge_types[kMaxBatchShards];
+  const int32_t* out_rows[kMaxBatchShards];   // or nullptr
+  void* out[kMaxBatchShards];
+  __host__ __device__ int total_tiles() const { return tile_base[shards]; }
+  __host__ __device__ int64_t total_rows() const { return (int64_t)tile_base[shards] * 32; }
+  __host__ __device__ int total_edges() const { return edge_base[shards]; }
+  __device__ int shard_of_tile(int tile) const {
+    int s = 0;
+    for (int k = 1; k < shards; ++k) s += tile >= tile_base[k] ? 1 : 0;
+    return s;
+  }
+  __device__ int shard_of_edge(int edge) const {
+    int s = 0;
+    for (int k = 1; k < shards; ++k) s += edge >= edge_base[k] ? 1 : 0;
+    return s;
+  }
+  __device__ int shard_of_count_block(int block) const {
+    int s = 0;
+    for (int k = 1; k < shards; ++k) s += block >= count_block_base[k] ? 1 : 0;
+    return s;
+  }
+};
+
 // COO -> CSR scratch (csr_build.hip, csr_finish.inc), all in the caller's workspace
 constexpr int kCsrSlots = 8;        // edge ids kept per row in the table (= plan slots)
 constexpr int kCsrTileRows = 32;    // rows finished by one 256-thread block (= layer tile)
 constexpr int kCsrLocalScanTiles = 4096;   // up to here the finish stage derives row_ptr itself
+constexpr uint32_t kCsrNoSource = 0xFFFFFFu;   // table entry: the edge's source is outside its shard
 struct CsrScratch {
   int32_t* count;              // [n + 1]   in-degree counters          (zero between calls)
   int32_t* overflow_count;     // [2]       list length, finish ticket  (zero between calls)
   int32_t* tile_sum;           // [tiles]   edges per 32 rows           (zero between calls)
-  int32_t* table;              // [n][kCsrSlots] first edge ids of every row
+  int2* table;                 // [n][kCsrSlots] first arrivals of every row: {edge id, global
+                               // source row | type << 24} (source 0xFFFFFF: outside its shard)
   int32_t* overflow;           // [e]       edge ids that found their row's slots taken
   int32_t* perm;               // [e]       hub rows: ids collected for the rank sort
 };
 size_t csr_clear_bytes(int64_t n);   // leading bytes of the workspace that must be zero
-bool csr_scan_free(int64_t n);       // the finish stage derives row_ptr itself
+bool csr_scan_free(int64_t n);       // the finish stage derives row_ptr itself (n: largest shard)
 CsrScratch carve_csr(void* base, int64_t n, int64_t e, int32_t** scan_sums, size_t* bytes);
 int launch_csr_clear(void* ws, int64_t n, hipStream_t s);
-int launch_csr_count_scan(const CsrScratch& w, int32_t* scan_sums, const int32_t* edge_index,
-                          int64_t n, int64_t e, int32_t* row_ptr, hipStream_t s);
+int launch_csr_count_scan(const CsrScratch& w, int32_t* scan_sums, const ShardTable& shards,
+                          bool scan_free, int32_t* row_ptr, int64_t rows, hipStream_t s);
+ShardTable single_shard(const float* x, const int32_t* edge_index, const uint8_t* edge_types,
+                        int64_t n, int64_t e, const int32_t* out_rows, void* out);
+int64_t largest_shard_nodes(const ShardTable& shards);
 
 int launch_build_csr(const int32_t* edge_index, const uint8_t* edge_types,
                      int64_t n, int64_t e, int32_t* row_ptr, int32_t* col,
@@ -213,11 +262,16 @@ size_t encode_f16_workspace_bytes(int64_t n, int64_t e);
 // COO in -> embeddings out: CSR build and encode as one sequence of launches, the last CSR
 // stage fused with the per-encode setup; the workspace's first csr_clear_bytes(n) bytes must
 // be zero (they are zero again afterwards)
-int launch_encode_coo_f16(const gfy_encoder* enc, const float* x, const int32_t* edge_index,
-                          const uint8_t* edge_types, int64_t n, int64_t e,
-                          const int32_t* out_rows, void* out, int out_dtype, int normalise,
-                          void* ws, size_t ws_bytes, hipStream_t s);
-size_t encode_coo_f16_workspace_bytes(int64_t n, int64_t e);
+int launch_encode_coo_f16(const gfy_encoder* enc, const ShardTable& shards, int out_dtype,
+                          int normalise, void* ws, size_t ws_bytes, hipStream_t s);
+size_t encode_coo_f16_workspace_bytes(int64_t padded_rows, int64_t e);
+
+// one GINE layer on a given hidden state, one of its phase tensors out (parity tests)
+size_t debug_layer_f16_workspace_bytes(int64_t n);
+int launch_debug_layer_f16(const gfy_encoder* enc, int layer, const void* hidden_in,
+                           const int32_t* row_ptr, const int32_t* col, const uint8_t* typ,
+                           int64_t n, int64_t e, int tap, void* out, void* ws, size_t ws_bytes,
+                           hipStream_t s);
 
 int launch_encode_f32(const gfy_encoder* enc, const float* x,
                       const int32_t* row_ptr, const int32_t* col,

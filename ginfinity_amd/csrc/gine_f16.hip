@@ -95,9 +95,7 @@ __device__ __forceinline__ float row16_sum32(float v) {
 // into libgfy.so proper.
 __device__ unsigned long long g_stamps[256][16];
 __device__ unsigned long long g_real[512][2];   // last launch: 100 MHz begin / end per workgroup
-// experiment: the first 256 workgroups of a layer launch start (blockIdx / 8) * g_stagger shader
-// cycles late, so that the CUs of an XCD run their fill bursts at different times
-__device__ int g_stagger;
+
 #define STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
 #else
 #define STAMP(var)
@@ -122,13 +120,13 @@ struct TileWalk {
 // input Linear: h0 = R(R(x) . Win^T + b)            (_model.py:67, api.py:237-238)
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ void input_linear_block(
-    const float* __restrict__ x, const f16* __restrict__ w_in /*[8][16][8] packed*/,
-    const f16* __restrict__ b_in, f16* __restrict__ h, int n, int block, int blocks) {
-  // 16 lanes per node, 8 channels per lane, block-stride over node groups.  The 2-KB
-  // weight matrix is staged in LDS once per workgroup, laid out [c][chunk][k]
-  // (channel = 8*chunk + c) so a wave's read of one c is 256 contiguous bytes; reading
-  // it per-channel-row from memory made every lane hit its own 128-B line (~64 cycles
-  // per load instruction, tools/probe.hip).
+    const ShardTable& shards, const f16* __restrict__ w_in /*[8][16][8] packed*/,
+    const f16* __restrict__ b_in, f16* __restrict__ h, int block, int blocks) {
+  // 16 lanes per row, 8 channels per lane, block-stride over row groups of the batch's global
+  // (padded) row space; padding rows get zeros.  The 2-KB weight matrix is staged in LDS once
+  // per workgroup, laid out [c][chunk][k] (channel = 8*chunk + c) so a wave's read of one c is
+  // 256 contiguous bytes; reading it per-channel-row from memory made every lane hit its own
+  // 128-B line (~64 cycles per load instruction, tools/probe.hip).
   __shared__ f16x8 ws[128];
   __shared__ f16x8 bs[16];
   if (threadIdx.x < 128) ws[threadIdx.x] = reinterpret_cast<const f16x8*>(w_in)[threadIdx.x];
@@ -136,29 +134,35 @@ __device__ __forceinline__ void input_linear_block(
   __syncthreads();
   const int chunk = threadIdx.x & 15;
   const f16x8 bias = bs[chunk];
+  const int64_t rows = shards.total_rows();
   const int64_t stride = (int64_t)blocks * (blockDim.x >> 4);
-  for (int64_t node = (int64_t)block * (blockDim.x >> 4) + (threadIdx.x >> 4); node < n;
-       node += stride) {
-    float xv[kInDim];
+  for (int64_t row = (int64_t)block * (blockDim.x >> 4) + (threadIdx.x >> 4); row < rows;
+       row += stride) {
+    const int shard = shards.shard_of_tile((int)(row >> 5));
+    const int64_t node = row - (int64_t)shards.tile_base[shard] * 32;   // shard-local
+    f16x8 out = zero8();
+    if (node < shards.nodes[shard]) {
+      const float* __restrict__ x = shards.x[shard];
+      float xv[kInDim];
 #pragma unroll
-    for (int k = 0; k < kInDim; ++k) xv[k] = (float)(f16)x[node * kInDim + k];
-    f16x8 out;
+      for (int k = 0; k < kInDim; ++k) xv[k] = (float)(f16)x[node * kInDim + k];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const f16x8 w = ws[c * 16 + chunk];
-      float acc = 0.f;
+      for (int c = 0; c < 8; ++c) {
+        const f16x8 w = ws[c * 16 + chunk];
+        float acc = 0.f;
 #pragma unroll
-      for (int k = 0; k < kInDim; ++k) acc = __builtin_fmaf(xv[k], (float)w[k], acc);
-      out[c] = (f16)(acc + (float)bias[c]);
+        for (int k = 0; k < kInDim; ++k) acc = __builtin_fmaf(xv[k], (float)w[k], acc);
+        out[c] = (f16)(acc + (float)bias[c]);
+      }
     }
-    *reinterpret_cast<f16x8*>(h + node * kHidden + chunk * 8) = out;
+    *reinterpret_cast<f16x8*>(h + row * kHidden + chunk * 8) = out;
   }
 }
 
 __global__ __launch_bounds__(256) void k_input_linear_f16(
-    const float* __restrict__ x, const f16* __restrict__ w_in, const f16* __restrict__ b_in,
-    f16* __restrict__ h, int n) {
-  input_linear_block(x, w_in, b_in, h, n, blockIdx.x, gridDim.x);
+    const ShardTable shards, const f16* __restrict__ w_in, const f16* __restrict__ b_in,
+    f16* __restrict__ h) {
+  input_linear_block(shards, w_in, b_in, h, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(256) void k_copy_rows_f16(const f16* __restrict__ s
 
 #include "csr_finish.inc"
 #include "gine_layer.inc"
-#include "gine_layer_p.inc"
+#include "gine_layer_q.inc"
 
 int persistent_grid(int num_tiles) {
   int g = num_tiles < 256 ? num_tiles : 256;
@@ -407,11 +411,6 @@ extern "C" int gfy_debug_real(unsigned long long* host /*[512][2]*/) {
              ? GFY_OK
              : GFY_ERR_HIP;
 }
-extern "C" int gfy_debug_set_stagger(int cycles) {
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_stagger), &cycles, sizeof(cycles)) == hipSuccess
-             ? GFY_OK
-             : GFY_ERR_HIP;
-}
 extern "C" int gfy_debug_stamps(unsigned long long* host /*[256][16]*/, int reset) {
   if (host && hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) != hipSuccess)
     return GFY_ERR_HIP;
@@ -424,17 +423,17 @@ extern "C" int gfy_debug_stamps(unsigned long long* host /*[256][16]*/, int rese
 }
 #endif
 
-// two hidden-state buffers, each padded with spare rows behind the last node
-static size_t h_buffer_bytes(int64_t n) {
-  return align_up((size_t)(n + 2 * kTile) * kHidden * sizeof(f16), 256);
+// two hidden-state buffers over the batch's padded rows, each with spare rows behind the last
+static size_t h_buffer_bytes(int64_t rows) {
+  return align_up((size_t)(rows + 2 * kTile) * kHidden * sizeof(f16), 256);
 }
 // ... plus one plan per 32-node tile (gine_layer.inc)
-static size_t plan_bytes(int64_t n) {
-  const int64_t tiles = (n + kLTile - 1) / kLTile;   // staged plans, then the global slot words
-  return align_up(global_words_offset((int)tiles) + (size_t)tiles * kGlobalWordsBytes, 256);
+static size_t plan_bytes(int64_t rows) {
+  return align_up((size_t)((rows + kLTile - 1) / kLTile) * kPlanBytes, 256);
 }
+static int64_t padded_rows(int64_t n) { return (n + kLTile - 1) / kLTile * kLTile; }
 size_t encode_f16_workspace_bytes(int64_t n, int64_t /*e*/) {
-  return 2 * h_buffer_bytes(n) + plan_bytes(n);
+  return 2 * h_buffer_bytes(padded_rows(n)) + plan_bytes(padded_rows(n));
 }
 
 // > 64 KB of dynamic LDS needs an opt-in per kernel and per DEVICE (a process may drive
@@ -442,19 +441,17 @@ size_t encode_f16_workspace_bytes(int64_t n, int64_t /*e*/) {
 static PerDeviceOnce g_layer_lds_opt_in;
 int prepare_device_f16() {   // gfy_encoder_create, with the encoder's device current
   return g_layer_lds_opt_in.run([]() -> int {
-#define GFY_OPT_IN(kernel)                                                                 \
+#define GFY_OPT_IN(kernel, bytes)                                                          \
   GFY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel),                \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes))
-    GFY_OPT_IN((k_gine_layer_f16<true, false>));
-    GFY_OPT_IN((k_gine_layer_f16<false, false>));
-    GFY_OPT_IN((k_gine_layer_f16<true, true>));
-    GFY_OPT_IN((k_gine_layer_f16<false, true>));
-    GFY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gine_layer_p<true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsBytes));
-    GFY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gine_layer_p<false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsBytes));
-    GFY_OPT_IN((k_gine_layer_d<true>));
-    GFY_OPT_IN((k_gine_layer_d<false>));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes))
+    GFY_OPT_IN((k_gine_layer_f16<true, false>), kLdsBytes);
+    GFY_OPT_IN((k_gine_layer_f16<false, false>), kLdsBytes);
+    GFY_OPT_IN((k_gine_layer_f16<true, true>), kLdsBytes);
+    GFY_OPT_IN((k_gine_layer_f16<false, true>), kLdsBytes);
+    GFY_OPT_IN((k_gine_layer_q<true>), kQLdsBytes);
+    GFY_OPT_IN((k_gine_layer_q<false>), kQLdsBytes);
+    GFY_OPT_IN((k_gine_layer_q<true, true>), kQLdsBytes);
+    GFY_OPT_IN(k_head_d, kLdsBytes);
 #undef GFY_OPT_IN
     return GFY_OK;
   });
@@ -463,56 +460,50 @@ int prepare_device_f16() {   // gfy_encoder_create, with the encoder's device cu
 // `coo` != nullptr: the CSR is finished inside the setup launch (gfy_encode_coo)
 struct CooInput {
   CsrScratch scratch;
-  const int32_t* edge_index;
-  const uint8_t* edge_types;
-  int64_t e;
+  bool scan_free;
   int32_t* row_ptr;
   int32_t* col;
   uint8_t* typ;
 };
 
-static int encode_f16_on(const gfy_encoder* enc, const float* x, const int32_t* row_ptr,
-                         const int32_t* col, const uint8_t* typ, const CooInput* coo, int64_t n,
-                         const int32_t* out_rows, void* out, int out_dtype, int normalise,
-                         int tap_stage, void* ws, size_t ws_bytes, hipStream_t s) {
-  const int64_t e = 0;
-  (void)e;
-  const size_t need = encode_f16_workspace_bytes(n, e);
+// One shard or a batch (ShardTable), CSR given (row_ptr / col / typ: one shard only) or finished
+// here from the counting kernel's table (coo).
+static int encode_f16_on(const gfy_encoder* enc, const ShardTable& shards, const int32_t* row_ptr,
+                         const int32_t* col, const uint8_t* typ, const CooInput* coo,
+                         int out_dtype, int normalise, int tap_stage, void* ws, size_t ws_bytes,
+                         hipStream_t s) {
+  const int64_t rows = shards.total_rows();
+  const size_t need = 2 * h_buffer_bytes(rows) + plan_bytes(rows);
   GFY_REQUIRE(ws_bytes >= need, GFY_ERR_WORKSPACE,
               "gfy_encode: workspace %zu < required %zu", ws_bytes, need);
-  GFY_REQUIRE(n <= (int64_t)1 << 24, GFY_ERR_UNSUPPORTED,
+  GFY_REQUIRE(rows <= (int64_t)1 << 24, GFY_ERR_UNSUPPORTED,
               "gfy_encode: fp16 path addresses rows with 32-bit byte offsets; "
-              "split micro-batches above 16,777,216 nodes (got %lld)", (long long)n);
+              "split micro-batches / batches above 16,777,216 nodes (got %lld)", (long long)rows);
   f16* ha = (f16*)ws;
-  f16* hb = (f16*)((char*)ws + h_buffer_bytes(n));
-  char* plans = (char*)ws + 2 * h_buffer_bytes(n);
-  const int num_tiles = (int)((n + kTile - 1) / kTile);   // stand-alone head kernel
-  const int grid = persistent_grid(num_tiles);
-  const int layer_tiles = (int)((n + kLTile - 1) / kLTile);
+  f16* hb = (f16*)((char*)ws + h_buffer_bytes(rows));
+  char* plans = (char*)ws + 2 * h_buffer_bytes(rows);
+  const int layer_tiles = shards.total_tiles();
   // one tile per wave, eight per workgroup, XCD x = workgroups x, x + 8, ... (gine_layer.inc)
   const int layer_grid = 8 * ((layer_tiles + 8 * kLWaves - 1) / (8 * kLWaves));
 
-  const int64_t items = n * 16;
+  const int64_t items = rows * 16;
   enc->mark(s, 0);
   {
     const int64_t blocks = (items + 255) / 256;
     const int linear_blocks = (int)(blocks > 2048 ? 2048 : blocks);
     if (tap_stage == 0)
-      k_input_linear_f16<<<linear_blocks, 256, 0, s>>>(x, enc->f16.w_in, enc->f16.b_in, ha,
-                                                       (int)n);
-    else if (coo && csr_scan_free(n))   // + last CSR stage (row offsets included) + tile plans
+      k_input_linear_f16<<<linear_blocks, 256, 0, s>>>(shards, enc->f16.w_in, enc->f16.b_in, ha);
+    else if (coo && coo->scan_free)   // + last CSR stage (row offsets included) + tile plans
       k_encode_setup_coo<false><<<layer_tiles + linear_blocks, 256, 0, s>>>(
-          x, enc->f16.w_in, enc->f16.b_in, ha, (int)n, coo->scratch, coo->row_ptr,
-          coo->edge_index, coo->edge_index + coo->e, coo->edge_types, coo->col, coo->typ, plans,
-          layer_tiles);
+          shards, enc->f16.w_in, enc->f16.b_in, ha, coo->scratch, coo->row_ptr, coo->col,
+          coo->typ, plans, layer_tiles);
     else if (coo)
       k_encode_setup_coo<true><<<layer_tiles + linear_blocks, 256, 0, s>>>(
-          x, enc->f16.w_in, enc->f16.b_in, ha, (int)n, coo->scratch, coo->row_ptr,
-          coo->edge_index, coo->edge_index + coo->e, coo->edge_types, coo->col, coo->typ, plans,
-          layer_tiles);
+          shards, enc->f16.w_in, enc->f16.b_in, ha, coo->scratch, coo->row_ptr, coo->col,
+          coo->typ, plans, layer_tiles);
     else            // + tile plans
       k_encode_setup<<<layer_tiles + linear_blocks, 256, 0, s>>>(
-          x, enc->f16.w_in, enc->f16.b_in, ha, (int)n, row_ptr, col, typ, plans, layer_tiles);
+          shards, enc->f16.w_in, enc->f16.b_in, ha, row_ptr, col, typ, plans, layer_tiles);
   }
   enc->mark(s, 1);
   const int stop = tap_stage >= 0 ? tap_stage : enc->layers;
@@ -521,45 +512,47 @@ static int encode_f16_on(const gfy_encoder* enc, const float* x, const int32_t* 
         ~0ull, 0, ~0ull, 0, ~0ull, 0, ~0ull, 0, ~0ull, 0, ~0ull, 0, ~0ull, 0, ~0ull, 0};
     GFY_CHECK_HIP(hipMemcpyAsync(enc->device_spans, init, sizeof init, hipMemcpyHostToDevice, s));
   }
-  // fp16 output of a full encode: the last layer's launch runs the head as well
+  // Which layer kernel: a launch that gives every CU more than one round of eight tiles (a
+  // large micro-batch, or a batch of shards) runs the persistent-rounds kernel
+  // (gine_layer_q.inc: the fills of round r + 1 under the arithmetic of round r, CUs de-phased
+  // by a start stagger) and the stand-alone head behind it; a single-round launch (the 60,000-
+  // node shard by itself) runs the round-2 kernel, whose last launch carries the head.
+  // GFY_OPT_LAYER_KERNEL forces either (A/B runs, parity tests).
+  const int tiles_per_xcd = (layer_tiles + 7) / 8;
+  const int wanted = (tiles_per_xcd + kLWaves - 1) / kLWaves, per_xcd = enc->cus / 8;
+  const int p_grid = 8 * (wanted < per_xcd ? wanted : per_xcd);
+  const int rounds = (wanted + per_xcd - 1) / per_xcd;
+  const bool persistent = enc->layer_kernel == 3 || (enc->layer_kernel < 0 && rounds > 1);
+  // start offsets only pay once a workgroup runs several rounds (the offset costs up to one
+  // round at the start of the launch)
+  const int stagger = enc->stagger >= 0 ? enc->stagger : rounds >= 3 ? 500 : 0;
+  // fp16 output of a full encode: the round-2 kernel's last launch runs the head as well
   // (GFY_OPT_SEPARATE_HEAD keeps the stand-alone head kernel: A/B runs and parity tests)
-  const bool persistent = enc->layer_kernel != 1;   // 0: eight free-running waves, 2: four
   const bool fuse_head =
       tap_stage < 0 && out_dtype == GFY_F16 && stop > 0 && !enc->separate_head && !persistent;
-  // persistent kernel: one workgroup of four waves per CU, every wave walks its own tiles
-  const int tiles_per_xcd = (layer_tiles + 7) / 8;
-  const int waves = enc->layer_kernel == 2 ? kPWaves : kLWaves;
-  const int wanted = (tiles_per_xcd + waves - 1) / waves, per_xcd = enc->cus / 8;
-  const int p_grid = 8 * (wanted < per_xcd ? wanted : per_xcd);
-  for (int l = 0; l < stop && persistent; ++l) {
-    int32_t* const spent = coo && l == 0 && csr_scan_free(n) ? coo->scratch.tile_sum : nullptr;
+  // rows the layer kernels may look up in row_ptr (the direct path of hub tiles): the caller's
+  // CSR has n + 1 entries, the one finished here covers the padded rows as well
+  const int csr_limit = coo ? (int)rows : shards.nodes[0];
+  const int32_t* const csr_rows = coo ? coo->row_ptr : row_ptr;
+  const int32_t* const csr_col = coo ? coo->col : col;
+  const uint8_t* const csr_typ = coo ? coo->typ : typ;
+  for (int l = 0; l < stop; ++l) {
+    int32_t* const spent = coo && l == 0 && coo->scan_free ? coo->scratch.tile_sum : nullptr;
     unsigned long long* const span = enc->timing == 3 ? enc->device_spans + 2 * l : nullptr;
-    if (enc->layer_kernel == 0 && enc->residual)
-      k_gine_layer_d<true><<<p_grid, kLThreads, kLdsBytes, s>>>(
-          enc->f16.layer[l], ha, hb, row_ptr, col, typ, plans, (int)n, layer_tiles, spent, span);
-    else if (enc->layer_kernel == 0)
-      k_gine_layer_d<false><<<p_grid, kLThreads, kLdsBytes, s>>>(
-          enc->f16.layer[l], ha, hb, row_ptr, col, typ, plans, (int)n, layer_tiles, spent, span);
-    else if (enc->residual)
-      k_gine_layer_p<true><<<p_grid, kPThreads, kPLdsBytes, s>>>(
-          enc->f16.layer[l], ha, hb, row_ptr, col, typ, plans, (int)n, layer_tiles, spent, span);
-    else
-      k_gine_layer_p<false><<<p_grid, kPThreads, kPLdsBytes, s>>>(
-          enc->f16.layer[l], ha, hb, row_ptr, col, typ, plans, (int)n, layer_tiles, spent, span);
-    f16* sw = ha;
-    ha = hb;
-    hb = sw;
-    enc->mark(s, 2 + l);
-  }
-  for (int l = 0; l < stop && !persistent; ++l) {
     const bool with_head = fuse_head && l == stop - 1;
 #define GFY_LAUNCH_LAYER(RES, HEAD)                                                          \
   k_gine_layer_f16<RES, HEAD><<<layer_grid, kLThreads, kLdsBytes, s>>>(                      \
-      enc->f16.layer[l], ha, hb, row_ptr, col, typ, plans, (int)n, layer_tiles, enc->f16.head, \
-      out_rows, (f16*)out, normalise,                                                        \
-      coo && l == 0 && csr_scan_free(n) ? coo->scratch.tile_sum : nullptr,                   \
-      enc->timing == 3 ? enc->device_spans + 2 * l : nullptr)
-    if (enc->residual && with_head) GFY_LAUNCH_LAYER(true, true);
+      enc->f16.layer[l], ha, hb, csr_rows, csr_col, csr_typ, plans, csr_limit, layer_tiles,  \
+      enc->f16.head, shards, normalise, spent, span)
+    if (persistent && enc->residual)
+      k_gine_layer_q<true><<<p_grid, kLThreads, kQLdsBytes, s>>>(
+          enc->f16.layer[l], ha, hb, csr_rows, csr_col, csr_typ, plans, csr_limit, layer_tiles,
+          stagger, spent, span);
+    else if (persistent)
+      k_gine_layer_q<false><<<p_grid, kLThreads, kQLdsBytes, s>>>(
+          enc->f16.layer[l], ha, hb, csr_rows, csr_col, csr_typ, plans, csr_limit, layer_tiles,
+          stagger, spent, span);
+    else if (enc->residual && with_head) GFY_LAUNCH_LAYER(true, true);
     else if (enc->residual) GFY_LAUNCH_LAYER(true, false);
     else if (with_head) GFY_LAUNCH_LAYER(false, true);
     else GFY_LAUNCH_LAYER(false, false);
@@ -569,10 +562,10 @@ static int encode_f16_on(const gfy_encoder* enc, const float* x, const int32_t* 
     hb = sw;
     enc->mark(s, 2 + l);
   }
-  if (tap_stage >= 0) {
-    const int64_t groups = n * 8;
+  if (tap_stage >= 0) {   // one shard: its rows, natural channel order
+    const int64_t groups = (int64_t)shards.nodes[0] * 8;
     int g = (int)((groups + 255) / 256);
-    k_copy_rows_f16<<<g > 2048 ? 2048 : g, 256, 0, s>>>(ha, (f16*)out, groups);
+    k_copy_rows_f16<<<g > 2048 ? 2048 : g, 256, 0, s>>>(ha, (f16*)shards.out[0], groups);
     GFY_CHECK_HIP(hipGetLastError());
     return GFY_OK;
   }
@@ -581,19 +574,33 @@ static int encode_f16_on(const gfy_encoder* enc, const float* x, const int32_t* 
     GFY_CHECK_HIP(hipGetLastError());
     return GFY_OK;
   }
-  const int head_lds = 2 * kTile * 256;
-  switch (out_dtype) {
-    case GFY_F16:
-      k_head_f16<f16><<<grid, kThreads, head_lds, s>>>(
-          enc->f16.head, ha, out_rows, (f16*)out, (int)n, num_tiles, normalise);
-      break;
-    case GFY_F32:
-      k_head_f16<float><<<grid, kThreads, head_lds, s>>>(
-          enc->f16.head, ha, out_rows, (float*)out, (int)n, num_tiles, normalise);
-      break;
-    default:
-      k_head_f16<double><<<grid, kThreads, head_lds, s>>>(
-          enc->f16.head, ha, out_rows, (double*)out, (int)n, num_tiles, normalise);
+  if (out_dtype == GFY_F16 && persistent) {
+    k_head_d<<<p_grid, kLThreads, kLdsBytes, s>>>(enc->f16.head, ha, shards, layer_tiles,
+                                                  normalise);
+  } else {   // the tiled stand-alone head, shard by shard (f32 / f64 output, A/B runs)
+    const int head_lds = 2 * kTile * 256;
+    for (int k = 0; k < shards.shards; ++k) {
+      const int n = shards.nodes[k];
+      const int num_tiles = (n + kTile - 1) / kTile;
+      const int grid = persistent_grid(num_tiles);
+      const f16* rows_k = ha + (size_t)shards.tile_base[k] * kLTile * kHidden;
+      switch (out_dtype) {
+        case GFY_F16:
+          k_head_f16<f16><<<grid, kThreads, head_lds, s>>>(
+              enc->f16.head, rows_k, shards.out_rows[k], (f16*)shards.out[k], n, num_tiles,
+              normalise);
+          break;
+        case GFY_F32:
+          k_head_f16<float><<<grid, kThreads, head_lds, s>>>(
+              enc->f16.head, rows_k, shards.out_rows[k], (float*)shards.out[k], n, num_tiles,
+              normalise);
+          break;
+        default:
+          k_head_f16<double><<<grid, kThreads, head_lds, s>>>(
+              enc->f16.head, rows_k, shards.out_rows[k], (double*)shards.out[k], n, num_tiles,
+              normalise);
+      }
+    }
   }
   enc->mark(s, 2 + enc->layers);
   GFY_CHECK_HIP(hipGetLastError());
@@ -606,12 +613,13 @@ int launch_encode_f16(const gfy_encoder* enc, const float* x,
                       const int32_t* out_rows, void* out, int out_dtype,
                       int normalise, int tap_stage, void* ws, size_t ws_bytes,
                       hipStream_t s) {
-  (void)e;
-  return encode_f16_on(enc, x, row_ptr, col, typ, nullptr, n, out_rows, out, out_dtype,
-                       normalise, tap_stage, ws, ws_bytes, s);
+  const ShardTable shards = single_shard(x, nullptr, nullptr, n, e, out_rows, out);
+  return encode_f16_on(enc, shards, row_ptr, col, typ, nullptr, out_dtype, normalise, tap_stage,
+                       ws, ws_bytes, s);
 }
 
-// workspace of gfy_encode_coo: [CSR scratch, counters first][row_ptr][col][typ][encode]
+// workspace of gfy_encode_coo / gfy_encode_coo_batch over `rows` padded rows and `e` edges:
+// [CSR scratch, counters first][row_ptr][col][typ][encode]
 struct CooWorkspace {
   CsrScratch scratch;
   int32_t* scan_sums;
@@ -621,37 +629,82 @@ struct CooWorkspace {
   void* encode;
   size_t encode_bytes, bytes;
 };
-static CooWorkspace carve_coo(void* base, int64_t n, int64_t e) {
+static CooWorkspace carve_coo(void* base, int64_t rows, int64_t e) {
   CooWorkspace w;
   size_t off = 0;
-  w.scratch = carve_csr(base, n, e, &w.scan_sums, &off);
+  w.scratch = carve_csr(base, rows, e, &w.scan_sums, &off);
   auto take = [&](size_t size) {
     void* p = base ? (char*)base + off : nullptr;
     off += align_up(size, 256);
     return p;
   };
-  w.row_ptr = (int32_t*)take((size_t)(n + 1) * 4);
+  w.row_ptr = (int32_t*)take((size_t)(rows + 1) * 4);
   w.col = (int32_t*)take((size_t)(e > 0 ? e : 1) * 4);
   w.typ = (uint8_t*)take((size_t)(e > 0 ? e : 1));
-  w.encode_bytes = encode_f16_workspace_bytes(n, e);
+  w.encode_bytes = 2 * h_buffer_bytes(rows) + plan_bytes(rows);
   w.encode = take(w.encode_bytes);
   w.bytes = off;
   return w;
 }
-size_t encode_coo_f16_workspace_bytes(int64_t n, int64_t e) { return carve_coo(nullptr, n, e).bytes; }
+size_t encode_coo_f16_workspace_bytes(int64_t rows, int64_t e) {
+  return carve_coo(nullptr, rows, e).bytes;
+}
 
-int launch_encode_coo_f16(const gfy_encoder* enc, const float* x, const int32_t* edge_index,
-                          const uint8_t* edge_types, int64_t n, int64_t e,
-                          const int32_t* out_rows, void* out, int out_dtype, int normalise,
-                          void* ws, size_t ws_bytes, hipStream_t s) {
-  const CooWorkspace w = carve_coo(ws, n, e);
+int launch_encode_coo_f16(const gfy_encoder* enc, const ShardTable& shards, int out_dtype,
+                          int normalise, void* ws, size_t ws_bytes, hipStream_t s) {
+  const CooWorkspace w = carve_coo(ws, shards.total_rows(), shards.total_edges());
   GFY_REQUIRE(ws_bytes >= w.bytes, GFY_ERR_WORKSPACE,
               "gfy_encode_coo: workspace %zu < required %zu", ws_bytes, w.bytes);
-  if (const int rc = launch_csr_count_scan(w.scratch, w.scan_sums, edge_index, n, e, w.row_ptr, s))
+  const bool scan_free = csr_scan_free(largest_shard_nodes(shards));
+  if (const int rc = launch_csr_count_scan(w.scratch, w.scan_sums, shards, scan_free, w.row_ptr,
+                                           shards.total_rows(), s))
     return rc;
-  const CooInput coo{w.scratch, edge_index, edge_types, e, w.row_ptr, w.col, w.typ};
-  return encode_f16_on(enc, x, w.row_ptr, w.col, w.typ, &coo, n, out_rows, out, out_dtype,
-                       normalise, -1, w.encode, w.encode_bytes, s);
+  const CooInput coo{w.scratch, scan_free, w.row_ptr, w.col, w.typ};
+  return encode_f16_on(enc, shards, nullptr, nullptr, nullptr, &coo, out_dtype, normalise, -1,
+                       w.encode, w.encode_bytes, s);
+}
+
+// ---- parity tap of one layer (gfy_debug_layer) ----------------------------------------------
+static size_t tap_bytes(int64_t rows) { return align_up((size_t)rows * kMlp * sizeof(f16), 256); }
+size_t debug_layer_f16_workspace_bytes(int64_t n) {
+  const int64_t rows = padded_rows(n);
+  return 2 * h_buffer_bytes(rows) + plan_bytes(rows) + tap_bytes(rows);
+}
+
+int launch_debug_layer_f16(const gfy_encoder* enc, int layer, const void* hidden_in,
+                           const int32_t* row_ptr, const int32_t* col, const uint8_t* typ,
+                           int64_t n, int64_t e, int tap, void* out, void* ws, size_t ws_bytes,
+                           hipStream_t s) {
+  GFY_REQUIRE(enc->residual, GFY_ERR_UNSUPPORTED,
+              "gfy_debug_layer: only the residual architecture has a tap instantiation");
+  const ShardTable shards = single_shard(nullptr, nullptr, nullptr, n, e, nullptr, out);
+  const int64_t rows = shards.total_rows();
+  GFY_REQUIRE(ws_bytes >= debug_layer_f16_workspace_bytes(n), GFY_ERR_WORKSPACE,
+              "gfy_debug_layer: workspace %zu < required %zu", ws_bytes,
+              debug_layer_f16_workspace_bytes(n));
+  f16* ha = (f16*)ws;
+  f16* hb = (f16*)((char*)ws + h_buffer_bytes(rows));
+  char* plans = (char*)ws + 2 * h_buffer_bytes(rows);
+  f16* taps = (f16*)(plans + plan_bytes(rows));
+  const int layer_tiles = shards.total_tiles();
+  auto copy_rows = [&](const f16* from, f16* to, int64_t groups) {
+    const int g = (int)((groups + 255) / 256);
+    k_copy_rows_f16<<<g > 2048 ? 2048 : g, 256, 0, s>>>(from, to, groups);
+  };
+  GFY_CHECK_HIP(hipMemsetAsync(ha, 0, h_buffer_bytes(rows), s));   // padding rows: zeros
+  copy_rows((const f16*)hidden_in, ha, n * 8);                      // natural -> stored order
+  k_encode_setup<<<layer_tiles, 256, 0, s>>>(shards, enc->f16.w_in, enc->f16.b_in, ha, row_ptr,
+                                             col, typ, plans, layer_tiles);   // plans only
+  const int tiles_per_xcd = (layer_tiles + 7) / 8;
+  const int wanted = (tiles_per_xcd + kLWaves - 1) / kLWaves, per_xcd = enc->cus / 8;
+  const int grid = 8 * (wanted < per_xcd ? wanted : per_xcd);
+  k_gine_layer_q<true, true><<<grid, kLThreads, kQLdsBytes, s>>>(
+      enc->f16.layer[layer], ha, hb, row_ptr, col, typ, plans, (int)n, layer_tiles, 0, nullptr,
+      nullptr, tap, taps);
+  if (tap == kTapNone) copy_rows(hb, (f16*)out, n * 8);
+  else copy_rows(taps, (f16*)out, n * (tap == kTapV ? 16 : 8));   // stored -> natural order
+  GFY_CHECK_HIP(hipGetLastError());
+  return GFY_OK;
 }
 
 }  // namespace gfy

@@ -76,6 +76,10 @@ class DeviceEncoder:
         # as nobody else writes to it (include/gfy.h), so it is never shared with _scratch
         self._coo_workspace: torch.Tensor | None = None
         self._coo_clean_nodes = 0      # the counters are known to be zero for n <= this
+        # the zeroed counters are only "zero again" for work enqueued behind the last call:
+        # a call on another stream first waits for that call (event), see encode_coo
+        self._coo_done: "torch.cuda.Event | None" = None
+        self._coo_stream: int | None = None
 
     # -- lifetime ---------------------------------------------------------------
     def close(self) -> None:
@@ -204,22 +208,30 @@ class DeviceEncoder:
                 out = torch.empty((rows, EMBEDDING_DIM), dtype=out_dtype, device=self.device)
             assert out.is_contiguous() and out.shape == (rows, EMBEDDING_DIM)
             need = lib.gfy_encode_coo_workspace_bytes(self._handle, nodes, edges)
+            stream = torch.cuda.current_stream(self.device)
             if self._coo_workspace is None or self._coo_workspace.numel() < need:
                 self._coo_workspace = torch.zeros(max(need, 1 << 20), dtype=torch.uint8,
                                                   device=self.device)
                 self._coo_clean_nodes = 1 << 62
+                self._coo_done, self._coo_stream = None, None   # zero-filled on THIS stream
+            elif self._coo_stream is not None and self._coo_stream != stream.cuda_stream:
+                stream.wait_event(self._coo_done)     # the last call ran on another stream
             scratch = self._coo_workspace
             if nodes > self._coo_clean_nodes:   # an earlier, smaller call's arrays lie where
                 native.check(lib.gfy_encode_coo_prepare(   # this call's counters will be
-                    _ptr(scratch), scratch.numel(), nodes, self._stream()),
+                    _ptr(scratch), scratch.numel(), nodes, stream.cuda_stream),
                     "gfy_encode_coo_prepare")
             self._coo_clean_nodes = 0           # until the call below has been enqueued
             native.check(lib.gfy_encode_coo(
                 self._handle, _ptr(node_features), _ptr(edge_index) if edges else None,
                 _ptr(edge_types) if edges else None, nodes, edges, _ptr(out_rows), _ptr(out),
                 _GFY_OF_TORCH[out.dtype], 1 if normalise else 0, _ptr(scratch),
-                scratch.numel(), self._stream()), "gfy_encode_coo")
+                scratch.numel(), stream.cuda_stream), "gfy_encode_coo")
             self._coo_clean_nodes = nodes
+            if self._coo_done is None:
+                self._coo_done = torch.cuda.Event()
+            self._coo_done.record(stream)
+            self._coo_stream = stream.cuda_stream
         return out
 
     def prepare_step(self, node_features: torch.Tensor, edge_index: torch.Tensor,
@@ -241,6 +253,9 @@ class DeviceEncoder:
         with torch.cuda.device(self.device):
             need = lib.gfy_encode_coo_workspace_bytes(handle, nodes, edges)
             scratch = torch.zeros(need, dtype=torch.uint8, device=self.device)   # cleared once
+            # the zero-fill ran on torch's current stream; the step will be launched on streams
+            # of the caller's choice (non-blocking ones do not wait for it): finish it now
+            torch.cuda.current_stream(self.device).synchronize()
         encode = lib.gfy_encode_coo
         p_ei = _ptr(edge_index) if edges else None
         p_et = _ptr(edge_types) if edges else None
@@ -254,6 +269,70 @@ class DeviceEncoder:
             if status != 0:
                 native.check(status, "gfy_encode_coo")
         return step
+
+    # -- a batch of shards in one sequence of launches (gfy_encode_coo_batch) -------------------
+    def _shard_array(self, shards) -> "ctypes.Array":
+        """``shards``: sequence of (node_features, edge_index, edge_types, out_rows or None,
+        out) device tensors -> the host array of gfy_shard descriptors."""
+        if not 1 <= len(shards) <= native.GFY_MAX_BATCH_SHARDS:
+            raise ValueError(f"a batch holds 1..{native.GFY_MAX_BATCH_SHARDS} shards, "
+                             f"got {len(shards)}")
+        array = (native.GfyShard * len(shards))()
+        for slot, (x, ei, et, rows, out) in zip(array, shards):
+            nodes, edges = int(x.shape[0]), int(et.numel())
+            assert x.dtype == torch.float32 and x.is_contiguous()
+            assert ei.dtype == torch.int32 and ei.is_contiguous() and tuple(ei.shape) == (2, edges)
+            assert et.dtype == torch.uint8 and et.is_contiguous()
+            assert out.is_contiguous() and out.shape[1] == EMBEDDING_DIM
+            assert rows is None or (rows.dtype == torch.int32 and rows.numel() == nodes)
+            slot.node_features, slot.out = _ptr(x), _ptr(out)
+            slot.edge_index = _ptr(ei) if edges else None
+            slot.edge_types = _ptr(et) if edges else None
+            slot.out_rows = _ptr(rows)
+            slot.n_nodes, slot.n_edges = nodes, edges
+        return array
+
+    def prepare_batch_step(self, shards, *, normalise: bool = True):
+        """``gfy_encode_coo_batch`` over device-resident shards as a pre-bound callable
+        ``step(stream_handle)``: one C-ABI call per batch, descriptors, workspace (cleared
+        here, once) and pointers resolved up front.  ``shards`` as for ``_shard_array``; all
+        outputs share one dtype."""
+        array = self._shard_array(shards)
+        count = len(shards)
+        out_code = _GFY_OF_TORCH[shards[0][4].dtype]
+        assert all(s[4].dtype == shards[0][4].dtype for s in shards)
+        lib, handle = self._lib, self._handle
+        with torch.cuda.device(self.device):
+            need = lib.gfy_encode_coo_batch_workspace_bytes(handle, array, count)
+            if need == 0:
+                native.check(native.GFY_ERR_INVALID, "gfy_encode_coo_batch_workspace_bytes")
+            scratch = torch.zeros(need, dtype=torch.uint8, device=self.device)
+            torch.cuda.current_stream(self.device).synchronize()      # see prepare_step
+        encode, p_ws, ws_bytes = lib.gfy_encode_coo_batch, _ptr(scratch), scratch.numel()
+        flag = 1 if normalise else 0
+        keep = (shards, array, scratch)
+
+        def step(stream_handle: int, _keep=keep) -> None:
+            status = encode(handle, array, count, out_code, flag, p_ws, ws_bytes, stream_handle)
+            if status != 0:
+                native.check(status, "gfy_encode_coo_batch")
+        return step
+
+    def encode_coo_batch(self, shards, *, out_dtype: torch.dtype = torch.float16,
+                         normalise: bool = True) -> list[torch.Tensor]:
+        """``shards``: sequence of (node_features, edge_index, edge_types, out_rows or None,
+        n_out or None) -> one [n_out, 128] device tensor per shard, from ONE sequence of
+        launches on the current stream (a fresh workspace per call: steady-state loops use
+        ``prepare_batch_step``)."""
+        with torch.cuda.device(self.device):
+            outs = [torch.empty((int(x.shape[0]) if kept is None else int(kept), EMBEDDING_DIM),
+                                dtype=out_dtype, device=self.device)
+                    for x, _ei, _et, _rows, kept in shards]
+            step = self.prepare_batch_step(
+                [(x, ei, et, rows, out) for (x, ei, et, rows, _k), out in zip(shards, outs)],
+                normalise=normalise)
+            step(self._stream())
+        return outs
 
     def hidden(self, node_features: torch.Tensor, csr: DeviceCsr,
                stage: int) -> torch.Tensor:
@@ -270,6 +349,25 @@ class DeviceEncoder:
                 _ptr(csr.col), _ptr(csr.typ), csr.nodes, csr.edges, stage,
                 _ptr(out), _ptr(scratch), scratch.numel(), self._stream()),
                 "gfy_encode_hidden")
+        return out
+
+    def debug_layer(self, hidden: torch.Tensor, csr: DeviceCsr, layer: int,
+                    tap: int = native.GFY_TAP_H) -> torch.Tensor:
+        """Parity tap (``gfy_debug_layer``): GINE layer ``layer`` run on the given hidden
+        state (fp16 [N,128], natural channel order — e.g. the reference's own recorded
+        tensor), one of its phase tensors back: ``native.GFY_TAP_H`` h', ``_Z`` z, ``_V`` v
+        ([N,256]), ``_W`` w, ``_Y`` y."""
+        assert hidden.dtype == torch.float16 and hidden.is_contiguous()
+        assert tuple(hidden.shape) == (csr.nodes, EMBEDDING_DIM)
+        width = 2 * EMBEDDING_DIM if tap == native.GFY_TAP_V else EMBEDDING_DIM
+        with torch.cuda.device(self.device):
+            out = torch.empty((csr.nodes, width), dtype=torch.float16, device=self.device)
+            need = self._lib.gfy_debug_layer_workspace_bytes(self._handle, csr.nodes, csr.edges)
+            scratch = self._scratch(need)
+            native.check(self._lib.gfy_debug_layer(
+                self._handle, int(layer), _ptr(hidden), _ptr(csr.row_ptr), _ptr(csr.col),
+                _ptr(csr.typ), csr.nodes, csr.edges, int(tap), _ptr(out), _ptr(scratch),
+                scratch.numel(), self._stream()), "gfy_debug_layer")
         return out
 
     # -- diagnostics -------------------------------------------------------------------

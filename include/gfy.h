@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GFY_ABI_VERSION 2
+#define GFY_ABI_VERSION 3
 
 enum gfy_status {
   GFY_OK = 0,
@@ -166,6 +166,36 @@ int gfy_encode_coo(gfy_encoder* encoder, const float* node_features,
                    int64_t n_edges, const int32_t* out_rows, void* out, int out_dtype,
                    int normalise, void* workspace, size_t workspace_bytes, void* stream);
 
+/* A BATCH of shards in one sequence of launches: what encode_graphs does micro-batch after
+ * micro-batch (api.py:211-230 calling _run_graph_shard, api.py:232-260) for up to
+ * GFY_MAX_BATCH_SHARDS micro-batches at once.  Shards never share edges (graph.py:392-395), so the
+ * kernels treat the batch as one graph in which every shard starts on a 32-row tile boundary; the
+ * result of every shard is bit-identical to gfy_encode_coo on that shard alone (the per-node
+ * arithmetic does not depend on what else is in the launch).  Why: a 60,000-node shard gives each
+ * of the 256 CUs less than one round of tiles, so a launch is mostly ramp, fill and drain; a
+ * batch runs the persistent-rounds layer kernel (GFY_OPT_LAYER_KERNEL) and pays those once.
+ *   shards_host   HOST array of n_shards descriptors; the pointers in them are DEVICE pointers
+ *                 with the meaning of the gfy_encode_coo arguments of the same name
+ *   workspace     gfy_encode_coo_batch_workspace_bytes(); its first
+ *                 gfy_encode_coo_batch_clear_bytes() bytes must be ZERO when the call starts and
+ *                 are zero again when it has run (hipMemset once; again when the shards' sizes
+ *                 change or anything else has written to it)                                  */
+#define GFY_MAX_BATCH_SHARDS 16
+typedef struct gfy_shard {
+  const float* node_features;
+  const int32_t* edge_index;
+  const uint8_t* edge_types;
+  const int32_t* out_rows;   /* or NULL */
+  void* out;
+  int64_t n_nodes, n_edges;
+} gfy_shard;
+size_t gfy_encode_coo_batch_workspace_bytes(const gfy_encoder* encoder,
+                                            const gfy_shard* shards_host, int n_shards);
+size_t gfy_encode_coo_batch_clear_bytes(const gfy_shard* shards_host, int n_shards);
+int gfy_encode_coo_batch(gfy_encoder* encoder, const gfy_shard* shards_host, int n_shards,
+                         int out_dtype, int normalise, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
 /* Debug/parity tap: copy the hidden state after `stage` into `out`
  * ([N][hidden] in the model dtype): stage 0 = input Linear, l+1 = after layer l.
  * Same arguments as gfy_encode; used by the stage-by-stage parity tests. */
@@ -174,6 +204,23 @@ int gfy_encode_hidden(gfy_encoder* encoder, const float* node_features,
                       const uint8_t* typ, int64_t n_nodes, int64_t n_edges,
                       int stage, void* out, void* workspace,
                       size_t workspace_bytes, void* stream);
+
+/* Debug/parity tap of ONE GINE layer (GINEConv + LayerNorm + residual, _model.py:39-46,69-71)
+ * run on a GIVEN hidden state — e.g. the reference's own recorded tensor, so that every layer
+ * and every phase is pinned by itself instead of through the layers before it:
+ *   hidden_in  fp16 [N][hidden], natural channel order (h of the previous layer, or h0)
+ *   tap        GFY_TAP_H: h' = R(h + y) [N][hidden];  GFY_TAP_Z: z = R(R(s h) + agg) after the
+ *              gather;  GFY_TAP_V: v = relu(R(BN(u))) [N][2 hidden];  GFY_TAP_W: w = R(v W1^T + b1);
+ *              GFY_TAP_Y: y = R(LayerNorm(w))
+ *   out        fp16, natural channel order.  fp16 model with the residual architecture only;
+ *              runs the persistent-rounds kernel's tap instantiation (same code otherwise).   */
+enum gfy_layer_tap { GFY_TAP_H = 0, GFY_TAP_Z = 1, GFY_TAP_V = 2, GFY_TAP_W = 3, GFY_TAP_Y = 4 };
+size_t gfy_debug_layer_workspace_bytes(const gfy_encoder* encoder, int64_t n_nodes,
+                                       int64_t n_edges);
+int gfy_debug_layer(gfy_encoder* encoder, int layer, const void* hidden_in,
+                    const int32_t* row_ptr, const int32_t* col, const uint8_t* typ,
+                    int64_t n_nodes, int64_t n_edges, int tap, void* out, void* workspace,
+                    size_t workspace_bytes, void* stream);
 
 /* Per-kernel device timing of gfy_encode (diagnostics; bench.py's roofline
  * figure).  While enabled, gfy_encode brackets each kernel with hipEvents on the
@@ -196,9 +243,30 @@ int gfy_encoder_get_timing(gfy_encoder* encoder, float* ms_host, int capacity,
 
 /* Diagnostic options of one encoder (no reference counterpart; results within the stated
  * tolerances for every setting).  Set between encodes, never read from the environment.
- *   GFY_OPT_SEPARATE_HEAD  1: head + normalise as its own launch even for fp16 output      */
-enum gfy_option { GFY_OPT_SEPARATE_HEAD = 2, GFY_OPT_LAYER_KERNEL = 3 };
+ *   GFY_OPT_SEPARATE_HEAD  1: head + normalise as its own launch even for fp16 output
+ *   GFY_OPT_LAYER_KERNEL   -1 (default): by the launch — persistent rounds when a CU gets more
+ *                          than one round of eight 32-node tiles, else the one-round kernel whose
+ *                          last launch carries the head; 1 / 3 force either
+ *   GFY_OPT_STAGGER        persistent rounds: start offset between the workgroups of an XCD in
+ *                          shader cycles; -1 (default): 500 from three rounds up, else 0          */
+enum gfy_option { GFY_OPT_SEPARATE_HEAD = 2, GFY_OPT_LAYER_KERNEL = 3, GFY_OPT_STAGGER = 4 };
 int gfy_encoder_set_option(gfy_encoder* encoder, int option, int value);
+
+/* ---- host (CPU) implementation --------------------------------------------------------
+ * The reference's default device is the CPU (api.py:64-76: Ginfinity.load(device="cpu")); these
+ * entry points serve it: the same rounding-point model in plain C++ (csrc/gine_host.cpp),
+ * threads over node blocks, no HIP call.  For the drop-in surface on a box without a GPU
+ * (BASELINE configs[0]) — not a fallback: a gfy_encoder never routes here.  ALL pointers are
+ * HOST pointers; gfy_host_encode returns when the result is written.  Arguments as
+ * gfy_encode_coo; `threads` <= 1 runs on the calling thread.                                */
+typedef struct gfy_host_encoder gfy_host_encoder;
+int gfy_host_encoder_create(const void* weight_pack_host, size_t bytes, int model_dtype,
+                            gfy_host_encoder** out);
+void gfy_host_encoder_destroy(gfy_host_encoder* encoder);
+int gfy_host_encode(const gfy_host_encoder* encoder, const float* node_features,
+                    const int32_t* edge_index, const uint8_t* edge_types, int64_t n_nodes,
+                    int64_t n_edges, const int32_t* out_rows, void* out, int out_dtype,
+                    int normalise, int threads);
 
 /* ---- all-pairs distance over 128-d embeddings ----------------------------------
  * No reference symbol (the aligner lives in the external `ginfinity-sw`;

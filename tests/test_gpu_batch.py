@@ -1,0 +1,136 @@
+"""gfy_encode_coo_batch: several shards in one sequence of launches (include/gfy.h) must give,
+shard by shard, the bytes gfy_encode_coo gives on that shard alone — the per-node arithmetic does
+not depend on what else is in the launch, whichever layer kernel the launch's size selects
+(one-round kernel with the fused head / persistent rounds + stand-alone head).
+
+Reference semantics: ``encode_graphs`` runs micro-batch after micro-batch through
+``_run_graph_shard`` (src/ginfinity/api.py:211-260); the reference's CPU output is invariant to
+the micro-batch layout, which is what makes batching legitimate.
+"""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import torch
+
+from ginfinity_amd import _native as native
+from ginfinity_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _device(engine, shard):
+    dev = engine.device
+    rows, kept = None, None
+    if shard.node_roles.any():
+        core = shard.node_roles == 0
+        kept = int(core.sum())
+        table = np.cumsum(core, dtype=np.int32) - np.int32(1)
+        table[~core] = -1
+        rows = torch.from_numpy(table).to(dev)
+    return (torch.from_numpy(np.ascontiguousarray(shard.node_features)).to(dev),
+            torch.from_numpy(np.ascontiguousarray(shard.edge_index)).to(dev),
+            torch.from_numpy(np.ascontiguousarray(shard.edge_types)).to(dev), rows, kept)
+
+
+@pytest.fixture(scope="module")
+def mixed_shards(rouskin_shard):
+    """Unequal sizes on purpose: a few hundred nodes, ~50 k nodes, a 1-node graph, a shard with
+    context nodes and hubs (in-degree > 8: the direct path), the 60k/300k synthetic shard."""
+    from ginfinity_amd import GraphBuilder, RNA
+    tiny = GraphBuilder().build_shard([RNA("A", "A", ".")])
+    return [rouskin_shard.slice(0, 4), rouskin_shard.slice(64, 400), tiny,
+            synthetic.arbitrary_shard(0), synthetic.roofline_shard(3)]
+
+
+def _single(engine, shard, out_dtype=torch.float16):
+    x, ei, et, rows, kept = _device(engine, shard)
+    return engine.encode_coo(x, ei, et, out_rows=rows, n_out=kept, out_dtype=out_dtype).cpu().numpy()
+
+
+@pytest.mark.parametrize("kernel", [-1, 1, 3])
+def test_batch_is_bit_identical_to_single_shards(gpu_encoder, mixed_shards, kernel):
+    engine = gpu_encoder._engine
+    try:
+        engine.set_option(native.GFY_OPT_LAYER_KERNEL, -1)
+        want = [_single(engine, shard) for shard in mixed_shards]
+        engine.set_option(native.GFY_OPT_LAYER_KERNEL, kernel)
+        got = engine.encode_coo_batch([_device(engine, shard) for shard in mixed_shards])
+        torch.cuda.synchronize()
+        for shard, a, b in zip(mixed_shards, got, want):
+            assert a.shape == b.shape
+            assert a.cpu().numpy().tobytes() == b.tobytes(), shard.node_count
+    finally:
+        engine.set_option(native.GFY_OPT_LAYER_KERNEL, -1)
+
+
+def test_batch_of_synthetic_shards_matches_the_reference_rows(gpu_encoder, golden):
+    """Twelve 60k/300k shards in one call (the benchmark's batch): shards 0 and 1 against the
+    rows the reference itself produced (tests/golden/synthetic.npz), the rest against the
+    single-shard path."""
+    engine = gpu_encoder._engine
+    shards = [synthetic.roofline_shard(seed) for seed in range(12)]
+    outs = engine.encode_coo_batch([_device(engine, shard) for shard in shards])
+    torch.cuda.synchronize()
+    g = golden("synthetic.npz")
+    for seed in (0, 1):
+        rows = g[f"seed{seed}.rows"]
+        got = outs[seed].cpu().numpy()[rows].astype(np.float64)
+        assert np.abs(got - g[f"seed{seed}.out.m16"].astype(np.float64)).max() <= 1e-3
+    for seed in (2, 7, 11):
+        assert outs[seed].cpu().numpy().tobytes() == _single(engine, shards[seed]).tobytes()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_batch_other_output_dtypes_equal_single(gpu_encoder, mixed_shards, dtype):
+    engine = gpu_encoder._engine
+    picked = mixed_shards[:4]
+    got = engine.encode_coo_batch([_device(engine, s) for s in picked], out_dtype=dtype)
+    torch.cuda.synchronize()
+    for shard, a in zip(picked, got):
+        assert a.cpu().numpy().tobytes() == _single(engine, shard, dtype).tobytes()
+
+
+def test_batch_with_the_fp32_model_equals_single(gpu_encoder_fp32, mixed_shards):
+    engine = gpu_encoder_fp32._engine
+    picked = mixed_shards[:3]
+    got = engine.encode_coo_batch([_device(engine, s) for s in picked], out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    for shard, a in zip(picked, got):
+        assert a.cpu().numpy().tobytes() == _single(engine, shard, torch.float32).tobytes()
+
+
+def test_prepared_batch_step_leaves_its_workspace_ready(gpu_encoder, mixed_shards):
+    """The counters of the CSR build are zero again after a call: the same pre-bound step gives
+    the same bytes call after call, on a stream of the caller's choice."""
+    engine = gpu_encoder._engine
+    inputs = [_device(engine, shard) for shard in mixed_shards[:4]]
+    outs = [torch.empty((x.shape[0] if kept is None else kept, 128), dtype=torch.float16,
+                        device=engine.device) for x, _ei, _et, _rows, kept in inputs]
+    step = engine.prepare_batch_step([(x, ei, et, rows, out)
+                                      for (x, ei, et, rows, _k), out in zip(inputs, outs)])
+    stream = torch.cuda.Stream(device=engine.device)
+    step(stream.cuda_stream)
+    stream.synchronize()
+    first = [o.cpu().numpy().copy() for o in outs]
+    for o in outs:
+        o.zero_()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        step(stream.cuda_stream)
+    stream.synchronize()
+    for a, b in zip(first, outs):
+        assert a.tobytes() == b.cpu().numpy().tobytes()
+
+
+def test_batch_argument_errors(gpu_encoder, mixed_shards):
+    engine = gpu_encoder._engine
+    one = _device(engine, mixed_shards[0])
+    with pytest.raises(ValueError, match="1..16 shards"):
+        engine.encode_coo_batch([])
+    with pytest.raises(ValueError, match="1..16 shards"):
+        engine.encode_coo_batch([one] * 17)
+    lib = native.library()
+    array = (native.GfyShard * 1)()
+    assert lib.gfy_encode_coo_batch(engine._handle, array, 1, native.GFY_F16, 1, None, 0,
+                                    None) == native.GFY_ERR_INVALID

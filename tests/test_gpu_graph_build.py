@@ -16,7 +16,7 @@ torch = pytest.importorskip("torch")
 @pytest.fixture(scope="module")
 def gpu_encoder():
     from ginfinity_amd import Ginfinity
-    return Ginfinity.load("cuda:0")
+    return Ginfinity.load("cuda:0", allow_nondeterministic_cuda=True)
 
 
 def _random_structure(rng, length, pair_bias=0.45):
@@ -185,7 +185,8 @@ def test_cli_embed_and_embed_graphs_write_the_reference_archives(tmp_path, capsy
     table.write_text("transcript_id\tsequence\tsecondary_structure\n" + "".join(
         f"{r.identifier}\t{r.sequence}\t{r.structure}\n" for r in records))
     direct = tmp_path / "direct.npz"
-    assert main(["embed", "--input", str(table), "--output", str(direct)]) == 0
+    gpu = ["--device", "cuda", "--allow-nondeterministic-cuda"]
+    assert main(["embed", "--input", str(table), "--output", str(direct), *gpu]) == 0
     printed = json.loads(capsys.readouterr().out)
     assert printed["records"] == 120
     manifest = json.loads((tmp_path / "direct.manifest.json").read_text())
@@ -197,7 +198,7 @@ def test_cli_embed_and_embed_graphs_write_the_reference_archives(tmp_path, capsy
     capsys.readouterr()
     staged = tmp_path / "staged.npz"
     assert main(["embed-graphs", "--input", str(graphs), "--output", str(staged),
-                 "--embedding-dtype", "float16"]) == 0
+                 "--embedding-dtype", "float16", *gpu]) == 0
     want = gpu_encoder.encode_many(records)
     with np.load(direct) as a, np.load(staged) as b:
         assert list(a.keys()) == [r.identifier for r in records] == list(b.keys())

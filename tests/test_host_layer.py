@@ -279,9 +279,10 @@ def test_checkpoint_loader_and_integrity(tmp_path, checkpoint):
         load_checkpoint(copy)
 
 
-def test_device_policy_has_no_cpu_compute_path():
-    with pytest.raises(ValueError, match="no CPU compute path"):
-        Ginfinity.load("cpu")
+def test_device_policy_is_the_reference_s():
+    """api.py:69-76 — 'cpu' (default) or 'cuda*'; CUDA needs the acknowledgement flag."""
+    with pytest.raises(ValueError, match="CUDA requires allow_nondeterministic_cuda=True"):
+        Ginfinity.load("cuda")
     with pytest.raises(ValueError, match="device must be"):
         Ginfinity.load("tpu")
     assert set(default_alignment_parameters()) == {

@@ -7,7 +7,7 @@ from ginfinity_amd import Ginfinity, GraphBuilder, read_rna_table
 from ginfinity_amd.api import microbatch_bounds
 recs = read_rna_table(Path(__file__).resolve().parents[1] / "tests/golden/rouskin_sample_6k.tsv")
 shard = GraphBuilder().build_shard(recs)
-enc = Ginfinity.load("cuda")
+enc = Ginfinity.load("cuda", allow_nondeterministic_cuda=True)
 enc.encode_graphs(shard.slice(0, 50))
 bounds = microbatch_bounds(shard.lengths, shard.edge_counts, 60000, 300000)
 def old():

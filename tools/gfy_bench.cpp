@@ -12,7 +12,6 @@
 #ifdef GFY_STAMPS
 extern "C" int gfy_debug_stamps(unsigned long long*, int);
 extern "C" int gfy_debug_real(unsigned long long*);
-extern "C" int gfy_debug_set_stagger(int);
 #endif
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
@@ -47,13 +46,12 @@ int main(int argc, char** argv) {
   }
   gfy_encoder* enc = nullptr;
   GK(gfy_encoder_create(pack.data(), bytes, GFY_F16, 0, &enc));
-#ifdef GFY_STAMPS
-  if (getenv("GFY_BENCH_STAGGER")) GK(gfy_debug_set_stagger(atoi(getenv("GFY_BENCH_STAGGER"))));
-#endif
   if (getenv("GFY_BENCH_SEPARATE_HEAD"))   // the last layer launch is then a plain one
     GK(gfy_encoder_set_option(enc, GFY_OPT_SEPARATE_HEAD, 1));
-  const int layer_kernel = getenv("GFY_BENCH_LAYER_KERNEL") ? atoi(getenv("GFY_BENCH_LAYER_KERNEL")) : 0;
-  GK(gfy_encoder_set_option(enc, GFY_OPT_LAYER_KERNEL, layer_kernel));   // 0 eight free-running waves, 1 round 2, 2 four waves
+  const int layer_kernel = getenv("GFY_BENCH_LAYER_KERNEL") ? atoi(getenv("GFY_BENCH_LAYER_KERNEL")) : -1;
+  GK(gfy_encoder_set_option(enc, GFY_OPT_LAYER_KERNEL, layer_kernel));
+  const int stagger = getenv("GFY_BENCH_STAGGER") ? atoi(getenv("GFY_BENCH_STAGGER")) : -1;
+  GK(gfy_encoder_set_option(enc, GFY_OPT_STAGGER, stagger));   // 0 eight free-running waves, 1 round 2, 2 four waves
   // graph: records of L nodes: backbone both ways, skip2 both ways, random matching both ways
   const int64_t recs = N / L;
   std::vector<int32_t> src, dst; std::vector<uint8_t> typ;
@@ -124,6 +122,7 @@ int main(int argc, char** argv) {
     for (int q = 0; q < lanes; ++q) {
       GK(gfy_encoder_create(pack.data(), bytes, GFY_F16, 0, &encs[q])); CK(hipStreamCreateWithFlags(&ss[q], hipStreamNonBlocking));
       GK(gfy_encoder_set_option(encs[q], GFY_OPT_LAYER_KERNEL, layer_kernel));
+      GK(gfy_encoder_set_option(encs[q], GFY_OPT_STAGGER, stagger));
       CK(hipMalloc(&outs[q], N * 128 * 2)); CK(hipMalloc(&wb[q], b3)); CK(hipMemset(wb[q], 0, b3));
     }
     auto step = [&](int i) {
@@ -161,17 +160,28 @@ int main(int argc, char** argv) {
     gfy_debug_stamps(&st[0][0], 0);
     double sum[16] = {0};
     for (int b = 0; b < 256; ++b) for (int k = 0; k < 16; ++k) sum[k] += (double)st[b][k];
-    if (layer_kernel != 1) {
-      const double tiles = sum[11] > 0 ? sum[11] : 1;
-      const char* names[6] = {"prologue (W0 -> registers, W1 + image + first stage -> LDS), per wave",
-                              "plan words + own rows + gather", "next stage: plan head + DMA issue",
-                              "update MLP (both products)", "LayerNorm + residual + store",
-                              "wait for the next stage"};
-      printf("persistent layer kernel, shader cycles (stamped wave of workgroups 0..255):\n");
-      printf("  %-72s %8.0f per launch\n", names[0], sum[0] / (256.0 * reps * 4));
-      for (int k = 1; k < 6; ++k) printf("  %-72s %8.0f per tile\n", names[k], sum[k] / tiles);
-      printf("  tiles per stamped wave and launch %.2f, whole wave %.0f cycles per launch\n",
-             tiles / (256.0 * reps * 4), sum[10] / (256.0 * reps * 4));
+    if (layer_kernel == 3 || (layer_kernel < 0 && N > 65536)) {
+      const double rounds = sum[11] > 0 ? sum[11] : 1;
+      const char* names[8] = {"prologue (image, first plan head + stage)", "own rows + gather",
+                              "[W0 | W1] over the stages + barrier", "update MLP (both products)",
+                              "next plan head requested + barrier (weights spent)",
+                              "next plan head read + stage DMA issue + slot words",
+                              "LayerNorm + residual + store", "wait for the next stage"};
+      printf("persistent-rounds layer kernel, shader cycles (stamped wave of workgroups 0..255):\n");
+      printf("  %-56s %8.0f per launch\n", names[0], sum[0] / (256.0 * reps * 4));
+      for (int k = 1; k < 8; ++k) printf("  %-56s %8.0f per round\n", names[k], sum[k] / rounds);
+      printf("  rounds per workgroup and launch %.2f, whole wave %.0f cycles per launch, %.0f per round\n",
+             rounds / (256.0 * reps * 4), sum[10] / (256.0 * reps * 4), sum[10] / rounds);
+      {   // the clock the chip held: shader cycles of the stamped wave / its workgroup's lifetime
+        static unsigned long long real[512][2];
+        gfy_debug_real(&real[0][0]);
+        double life = 0; int used = 0;
+        for (int b = 0; b < 256; ++b)
+          if (real[b][1] > real[b][0]) life += (real[b][1] - real[b][0]) / 100.0, ++used;
+        if (used)
+          printf("  last launch: workgroup lifetime %.1f us (mean of %d) -> %.2f GHz shader clock while it ran\n",
+                 life / used, used, sum[10] / (256.0 * reps * 4) / (life / used) / 1e3);
+      }
     } else {
       const double plain = sum[11], headed = sum[13], all = plain + headed;
       const char* names[10] = {"plan + own rows (hop 1)", "far rows DMA + wait (hop 2)", "barrier 1",

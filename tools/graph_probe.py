@@ -9,7 +9,7 @@ from ginfinity_amd import Ginfinity, synthetic
 
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
-enc = Ginfinity.load("cuda:0")._engine
+enc = Ginfinity.load("cuda:0", allow_nondeterministic_cuda=True)._engine
 s = synthetic.roofline_shard(0)
 x = torch.from_numpy(s.node_features).to(dev)
 ei = torch.from_numpy(s.edge_index).to(dev)

@@ -7,7 +7,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from ginfinity_amd import Ginfinity, synthetic
 
 dev = torch.device("cuda", 0)
-enc = Ginfinity.load("cuda:0")._engine
+enc = Ginfinity.load("cuda:0", allow_nondeterministic_cuda=True)._engine
 s = synthetic.roofline_shard(0)
 x = torch.from_numpy(s.node_features).to(dev)
 ei = torch.from_numpy(s.edge_index).to(dev)

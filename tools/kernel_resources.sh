@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../ginfinity_amd/csrc"
 OUT=$(mktemp -d)
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math \
-  -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form "$@" --save-temps=obj -c gine_f16.hip -o "$OUT/gine_f16.o"
+  -Wall -Wno-unused-function "$@" --save-temps=obj -c gine_f16.hip -o "$OUT/gine_f16.o"
 python3 - "$OUT/gine_f16-hip-amdgcn-amd-amdhsa-gfx950.s" <<'PY'
 import re, sys
 text = open(sys.argv[1]).read()
