@@ -218,6 +218,7 @@ struct ShardTable {
 constexpr int kCsrSlots = 8;        // edge ids kept per row in the table (= plan slots)
 constexpr int kCsrTileRows = 32;    // rows finished by one 256-thread block (= layer tile)
 constexpr int kCsrLocalScanTiles = 4096;   // up to here the finish stage derives row_ptr itself
+constexpr int kCsrStageFarRows = 40;   // out-of-tile rows a gather stage holds (= kLFar, gine_layer.inc)
 constexpr uint32_t kCsrNoSource = 0xFFFFFFu;   // table entry: the edge's source is outside its shard
 struct CsrScratch {
   int32_t* count;              // [n + 1]   in-degree counters          (zero between calls)
