@@ -65,29 +65,55 @@ def microbatch_bounds(lengths: Sequence[int], edge_counts: Sequence[int],
     """Greedy contiguous packing of records into micro-batches, as
     ``encode_graphs`` does it (api.py:211-230): a record joins the current
     batch unless that would exceed either limit; a batch always holds at least
-    one record."""
+    one record.  Same boundaries as the reference's record-by-record loop, found
+    per micro-batch by two binary searches over the running sums (the loop over
+    5,840 records was 1 ms of every call)."""
+    total = len(lengths)
+    if total == 0:
+        return []
+    nodes = np.concatenate(([0], np.cumsum(np.asarray(lengths, dtype=np.int64))))
+    edges = np.concatenate(([0], np.cumsum(np.asarray(edge_counts, dtype=np.int64))))
     bounds: list[tuple[int, int]] = []
-    start, total = 0, len(lengths)
+    start = 0
     while start < total:
-        nodes, edges, stop = lengths[start], edge_counts[start], start + 1
-        while (stop < total and nodes + lengths[stop] <= max_batch_nodes
-               and edges + edge_counts[stop] <= max_batch_edges):
-            nodes += lengths[stop]
-            edges += edge_counts[stop]
-            stop += 1
+        # the largest stop with nodes[stop] - nodes[start] <= limit (and the same for edges)
+        by_nodes = int(np.searchsorted(nodes, nodes[start] + max_batch_nodes, side="right")) - 1
+        by_edges = int(np.searchsorted(edges, edges[start] + max_batch_edges, side="right")) - 1
+        stop = max(start + 1, min(by_nodes, by_edges, total))
         bounds.append((start, stop))
         start = stop
     return bounds
 
 
-class _Downloader:
-    """Device block → fresh (pageable) host array through a small ring of pinned staging
-    buffers: the DMA runs at PCIe speed into pinned memory and the copy out of it is a plain
-    memcpy — two worker threads, each with its own stream, so two memcpys and a DMA overlap
-    (one pageable ``tensor.cpu()`` is staged by a single runtime thread, ≈14 GB/s).  The
-    caller gets ordinary numpy memory: nothing stays pinned on its behalf."""
+def _advise_huge_pages(block: np.ndarray) -> None:
+    """Ask for transparent huge pages under a large, freshly allocated result block: its first
+    touch (by the copier threads) then takes a fault per 2 MB instead of one per 4 KB — 56,000
+    faults, 11 ms on one thread, for the 230 MB of config 2.  Best effort: not Linux, THP off
+    or a small block → nothing happens."""
+    try:
+        import ctypes
+        libc = ctypes.CDLL(None, use_errno=True)
+        huge = 2 << 20
+        begin = block.ctypes.data
+        first = -(-begin // huge) * huge
+        last = (begin + block.nbytes) // huge * huge
+        if last > first:
+            libc.madvise(ctypes.c_void_p(first), ctypes.c_size_t(last - first), 14)  # MADV_HUGEPAGE
+    except Exception:       # pragma: no cover - advisory only
+        pass
 
-    def __init__(self, device: torch.device, *, threads: int = 2, slots: int = 3) -> None:
+
+class _Downloader:
+    """Device block → the caller's (pageable) host memory through a ring of pinned staging
+    buffers: the DMA runs at PCIe speed into pinned memory and the copy out of it is a plain
+    memcpy (numpy releases the GIL for it) — six worker threads, each with its own stream, so
+    several memcpys and DMAs overlap (one pageable ``tensor.cpu()`` is staged by a single
+    runtime thread, ≈14 GB/s; two workers reached 17–19 GB/s, profiles/r02_api_bench.json).
+    The destination is a row range of ONE host block per ``encode_graphs`` call, first touched
+    (page-faulted) by the workers themselves, in parallel.  The caller gets ordinary numpy
+    memory: nothing stays pinned on its behalf."""
+
+    def __init__(self, device: torch.device, *, threads: int = 6, slots: int = 8) -> None:
         self._device = device
         self._free: "queue.SimpleQueue[torch.Tensor | None]" = queue.SimpleQueue()
         for _ in range(slots):
@@ -100,11 +126,14 @@ class _Downloader:
         torch.cuda.set_device(self._device)
         torch.cuda.set_stream(torch.cuda.Stream(device=self._device))
 
-    def submit(self, block: torch.Tensor, ready: "torch.cuda.Event", finish):
-        """Future of ``finish(host_array)``; ``block`` is read once ``ready`` has happened."""
-        return self._pool.submit(self._run, block, ready, finish)
+    def submit(self, block: torch.Tensor, ready: "torch.cuda.Event", finish,
+               destination: np.ndarray | None = None):
+        """Future of ``finish(host_array)``; ``block`` is read once ``ready`` has happened.
+        ``destination``: where the rows go (same shape and dtype as ``block``); a fresh array
+        otherwise."""
+        return self._pool.submit(self._run, block, ready, finish, destination)
 
-    def _run(self, block: torch.Tensor, ready: "torch.cuda.Event", finish):
+    def _run(self, block: torch.Tensor, ready: "torch.cuda.Event", finish, destination):
         nbytes = block.numel() * block.element_size()
         staging = self._free.get()
         try:
@@ -116,7 +145,9 @@ class _Downloader:
             view = staging[:nbytes].view(block.dtype).view(block.shape)
             view.copy_(block, non_blocking=True)
             stream.synchronize()
-            host = np.empty(tuple(block.shape), dtype=view.numpy().dtype)
+            host = destination
+            if host is None:
+                host = np.empty(tuple(block.shape), dtype=view.numpy().dtype)
             np.copyto(host, view.numpy())
         finally:
             self._free.put(staging)
@@ -125,31 +156,43 @@ class _Downloader:
 
 class _Uploader:
     """Several small host arrays → device tensors with ONE copy: they are packed into a
-    pinned staging buffer (ring of three, each guarded by the event of its last copy) and go
-    up as a single asynchronous H2D; the device tensors are views of one allocation.  Five
-    pageable ``tensor.to(device)`` per micro-batch were 0.4 ms of the launching thread."""
+    pinned staging buffer (ring, each slot guarded by the event of its last copy) and go up
+    as a single asynchronous H2D; the device tensors are views of one allocation.  Five
+    pageable ``tensor.to(device)`` per micro-batch were 0.4 ms of the launching thread.
+
+    ``pack`` (host memcpy into pinned memory, edge rebasing, the edge range check of the
+    slice) may run on a worker thread ahead of the launching thread, which then only calls
+    ``send``: with 61 MB of inputs for the 897,588-node shard the packing was 4 of the
+    launching thread's 12 ms."""
 
     _TORCH = {np.dtype(np.uint8): torch.uint8, np.dtype(np.int64): torch.int64,
               np.dtype(np.int32): torch.int32, np.dtype(np.float32): torch.float32}
 
-    def __init__(self, device: torch.device, slots: int = 3) -> None:
+    def __init__(self, device: torch.device, slots: int = 6) -> None:
         self._device = device
         self._staging: list[torch.Tensor | None] = [None] * slots
         self._copied: list["torch.cuda.Event | None"] = [None] * slots
         self._next = 0
+        self.slots = slots
 
-    def __call__(self, arrays: Sequence) -> list[torch.Tensor | None]:
-        """``arrays``: numpy arrays, ``None``, or ``(array, scalar)`` = upload ``array - scalar``
-        (edge indices rebased to the micro-batch's first node, graph.py:414-444)."""
-        rebases = [item[1] if isinstance(item, tuple) else None for item in arrays]
+    def reserve(self) -> int:
+        """Next staging slot (called by the launching thread, in micro-batch order)."""
+        slot = self._next
+        self._next = (slot + 1) % len(self._staging)
+        return slot
+
+    def pack(self, slot: int, arrays: Sequence):
+        """``arrays``: numpy arrays, ``None``, or ``(array, scalar, lo, hi)`` = pack
+        ``array - scalar`` after checking that every value lies in [lo, hi) (edge indices
+        rebased to the micro-batch's first node, graph.py:414-444, with the range check of
+        graph.py:318-321 on the slice).  Thread-safe per slot."""
+        rebases = [item[1:] if isinstance(item, tuple) else None for item in arrays]
         arrays = [item[0] if isinstance(item, tuple) else item for item in arrays]
         offsets, total = [], 0
         for array in arrays:
             offsets.append(total)
             if array is not None:
                 total += -(-array.nbytes // 256) * 256
-        slot = self._next
-        self._next = (slot + 1) % len(self._staging)
         if self._copied[slot] is not None:
             self._copied[slot].synchronize()          # the slot's last copy has left it
         staging = self._staging[slot]
@@ -165,7 +208,16 @@ class _Uploader:
                 if rebase is None:
                     np.copyto(target, array)
                 else:
-                    np.subtract(array, rebase, out=target)
+                    base, low, high = rebase
+                    np.subtract(array, base, out=target)
+                    if int(target.min()) < low - base or int(target.max()) >= high - base:
+                        raise GraphValidationError("edge index outside shard node range")
+        return slot, arrays, offsets, total
+
+    def send(self, packed) -> list[torch.Tensor | None]:
+        """The packed slot → device tensors (views of one allocation), on the current stream."""
+        slot, arrays, offsets, total = packed
+        staging = self._staging[slot]
         on_device = torch.empty(max(total, 1), dtype=torch.uint8, device=self._device)
         on_device[:total].copy_(staging[:total], non_blocking=True)
         done = torch.cuda.Event()
@@ -179,6 +231,9 @@ class _Uploader:
             flat = on_device[offset:offset + array.nbytes].view(self._TORCH[array.dtype])
             views.append(flat.view(array.shape))
         return views
+
+    def __call__(self, arrays: Sequence) -> list[torch.Tensor | None]:
+        return self.send(self.pack(self.reserve(), arrays))
 
 
 class Ginfinity:
@@ -295,10 +350,14 @@ class Ginfinity:
             self._uploader = _Uploader(device)
         pending, verdicts = [], []
         bounds = microbatch_bounds(lengths, edge_counts, max_batch_nodes, max_batch_edges)
+        produced = np.dtype(embedding_dtype) if exact else np.dtype(np.float64)
+        host_block = np.empty((int(text.node_ptr[-1] - text.node_ptr[0]),
+                               self.embedding_dimension), dtype=produced)
+        _advise_huge_pages(host_block)
         # the positional columns (numpy sin / cos, GIL released) of later micro-batches are
         # computed on a second helper thread while this one uploads and launches
         if self._preparer is None:
-            self._preparer = ThreadPoolExecutor(max_workers=1,
+            self._preparer = ThreadPoolExecutor(max_workers=3,
                                                 thread_name_prefix="ginfinity-prep")
         columns_of = [self._preparer.submit(text.positional, a, b) for a, b in bounds]
         for (start, stop), columns_job in zip(bounds, columns_of):
@@ -317,11 +376,15 @@ class Ginfinity:
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(device))
             verdicts.append((start, first_invalid))
-            pending.append(self._copier.submit(
-                block, ready, self._splitter(lengths[start:stop], embedding_dtype, exact)))
+            row = n0 - int(text.node_ptr[0])
+            pending.append((self._copier.submit(block, ready, lambda host: None,
+                                                host_block[row:row + n1 - n0]),
+                            row, n1 - n0, lengths[start:stop]))
         outputs: list[np.ndarray] = []
-        for job in pending:
-            outputs.extend(job.result())
+        for job, row, kept, counts in pending:     # views cut here, as the copies land
+            job.result()
+            outputs.extend(self._splitter(counts, embedding_dtype, exact)(
+                host_block[row:row + kept]))
         for start, first_invalid in verdicts:
             bad = int(first_invalid.item())
             if bad >= 0:
@@ -375,31 +438,36 @@ class Ginfinity:
             for start, stop in bounds:
                 outputs.extend(self._run_graph_shard(shard.slice(start, stop), embedding_dtype))
             return outputs
-        # Several micro-batches: the copy of batch k back to the host (15 MB, the long pole:
-        # the kernels take 0.15 ms) runs on a helper thread while this thread slices,
-        # uploads and launches batch k+1 — PCIe is full duplex.  Compute stays on ONE
-        # stream in batch order (one encoder, one workspace).
+        # Several micro-batches, three kinds of thread: PACKERS slice the shard, rebase and
+        # range-check the edges and copy the micro-batch's arrays into pinned staging (up to
+        # `slots - 1` micro-batches ahead); THIS thread uploads, launches and records events
+        # (~0.1 ms per micro-batch); COPIERS bring the embeddings back through their pinned ring
+        # into one host block.  PCIe is full duplex and the host copies run in parallel, so the
+        # call is bound by the 230 MB of D2H (config 2), not by a thread.  Compute stays on ONE
+        # stream in micro-batch order (one encoder, one workspace).
         torch_dtype, _code, exact = device_output_dtype(embedding_dtype)
         if self._copier is None:
             self._copier = _Downloader(self._engine.device)
         if self._uploader is None:
             self._uploader = _Uploader(self._engine.device)
-        pending = []
+        if self._preparer is None:
+            self._preparer = ThreadPoolExecutor(max_workers=4,
+                                                thread_name_prefix="ginfinity-prep")
+        uploader = self._uploader
         core_counts = shard.core_counts
-        for start, stop in bounds:
+        produced = np.dtype(embedding_dtype) if exact else np.dtype(np.float64)
+        host_block = np.empty((int(sum(core_counts)), self.embedding_dimension), dtype=produced)
+        _advise_huge_pages(host_block)
+
+        def prepare(slot: int, start: int, stop: int):
             # the arrays of GraphShard.slice(start, stop) (graph.py:414-444: edge indices
             # rebased to the first node of the range) without building — and re-validating —
-            # a GraphShard per micro-batch: that was 11 of this thread's 15 ms
+            # a GraphShard per micro-batch; the one check of GraphShard.__post_init__ that
+            # depends on the slice (graph.py:318-321 after the rebasing: an edge that leaves
+            # the micro-batch's node range, which the whole-shard range check cannot see) is
+            # made on the way into pinned memory and refused exactly as the reference refuses it
             n0, n1 = int(shard.node_ptr[start]), int(shard.node_ptr[stop])
             e0, e1 = int(shard.edge_ptr[start]), int(shard.edge_ptr[stop])
-            # ... except the one check of GraphShard.__post_init__ that depends on the slice
-            # (graph.py:318-321 after the rebasing of 414-444): an edge that leaves the
-            # micro-batch's node range — an edge across graphs that the whole-shard range
-            # check cannot see — is refused exactly as the reference refuses it
-            if e1 > e0:
-                window = shard.edge_index[:, e0:e1]
-                if int(window.min()) < n0 or int(window.max()) >= n1:
-                    raise GraphValidationError("edge index outside shard node range")
             roles = shard.node_roles[n0:n1]
             rows, kept = None, n1 - n0
             if roles.any():                      # context nodes: dropped at the head's store
@@ -407,32 +475,52 @@ class Ginfinity:
                 kept = int(np.count_nonzero(core))
                 rows = np.cumsum(core, dtype=np.int32) - np.int32(1)
                 rows[~core] = -1
-            features, edge_index, edge_types, out_rows = self._uploader(
-                (shard.node_features[n0:n1], (shard.edge_index[:, e0:e1], np.int32(n0)),
-                 shard.edge_types[e0:e1], rows))
+            packed = uploader.pack(slot, (
+                shard.node_features[n0:n1], (shard.edge_index[:, e0:e1], np.int32(n0), n0, n1),
+                shard.edge_types[e0:e1], rows))
+            return packed, kept
+
+        ahead = max(1, uploader.slots - 1)
+        jobs: list = []
+        pending = []
+        first_row = 0
+        for index, (start, stop) in enumerate(bounds):
+            while len(jobs) < len(bounds) and len(jobs) <= index + ahead - 1:
+                a, b = bounds[len(jobs)]
+                jobs.append(self._preparer.submit(prepare, uploader.reserve(), a, b))
+            packed, kept = jobs[index].result()
+            features, edge_index, edge_types, out_rows = uploader.send(packed)
             block = self._engine.encode_coo(features, edge_index, edge_types,
                                             out_rows=out_rows, n_out=kept,
                                             out_dtype=torch_dtype, normalise=True)
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(block.device))
-            pending.append(self._copier.submit(
-                block, ready,
-                self._splitter(core_counts[start:stop], embedding_dtype, exact)))
+            # (the workers run no interpreter-level loops: a worker cutting 400 views holds the
+            # GIL for 0.3 ms at a time and this thread, which needs it between every two
+            # enqueues, took 0.6 ms per micro-batch instead of 0.1)
+            pending.append((self._copier.submit(
+                block, ready, lambda host: None, host_block[first_row:first_row + kept]),
+                first_row, kept, core_counts[start:stop]))
+            first_row += kept
+        # the per-record views are cut here, micro-batch by micro-batch as the copies land
         outputs: list[np.ndarray] = []
-        for job in pending:
-            outputs.extend(job.result())
+        for job, row, kept, counts in pending:
+            job.result()
+            outputs.extend(self._splitter(counts, embedding_dtype, exact)(
+                host_block[row:row + kept]))
         return outputs
 
     def _splitter(self, core_counts, embedding_dtype: np.dtype, exact: bool):
         """host block → the per-record arrays of one micro-batch (views of the block, or
         copies with ``independent_outputs``)."""
-        cuts = np.cumsum(core_counts)[:-1]
+        ends = np.cumsum(core_counts).tolist()
+        starts = [0] + ends[:-1]
         independent = self.independent_outputs
 
         def finish(host: np.ndarray) -> list[np.ndarray]:
             if not exact:
                 host = host.astype(embedding_dtype)
-            parts = np.split(host, cuts, axis=0)
+            parts = [host[a:b] for a, b in zip(starts, ends)]   # (np.split: 3x the time)
             return [part.copy() for part in parts] if independent else parts
         return finish
 
