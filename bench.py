@@ -79,7 +79,7 @@ def parse() -> argparse.Namespace:
     parser.add_argument("--warmup", type=int, default=100)
     parser.add_argument("--streams", type=int, default=2,
                         help="batches in flight per GPU (HIP streams)")
-    parser.add_argument("--batch", type=int, default=12,
+    parser.add_argument("--batch", type=int, default=4,
                         help="shards per launch sequence (gfy_encode_coo_batch, 1..16)")
     parser.add_argument("--distance-rows", type=int, default=1_000_000,
                         help="rows of the all-pairs nearest leg (0 = skip it)")
@@ -98,29 +98,49 @@ def parse() -> argparse.Namespace:
     return parser.parse_args()
 
 
+def visible_gpus() -> int:
+    """GPUs this process may use, WITHOUT starting the HIP runtime (torch.cuda.device_count()
+    opens /dev/kfd unless amdsmi is importable): the KFD topology lists every node, GPUs are
+    the ones with SIMDs; HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES
+    narrow the list as the runtime would."""
+    nodes = Path("/sys/class/kfd/kfd/topology/nodes")
+    count = 0
+    try:
+        for node in sorted(nodes.iterdir(), key=lambda p: int(p.name)):
+            text = (node / "properties").read_text()
+            fields = dict(line.split() for line in text.splitlines() if len(line.split()) == 2)
+            if int(fields.get("simd_count", "0")) > 0:
+                count += 1
+    except (OSError, ValueError):
+        return torch.cuda.device_count()            # no KFD topology: ask the runtime
+    for name in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        value = os.environ.get(name)
+        if value is not None:
+            listed = [v for v in value.split(",") if v.strip() != ""]
+            count = min(count, len(listed))
+    return count
+
+
 def launch_ranks(args: argparse.Namespace) -> "NoReturn":
     """``python bench.py --gpus N`` outside torchrun: start N fresh rank processes and relay
     rank 0's line.  The reference's model is one process per shard under an external
     scheduler (docs/GRAPH_PIPELINE.md:22-24); here the scheduler is torch.distributed.run,
-    one rank per GPU.  This process never touches HIP (``torch.cuda.device_count()`` does
-    not initialise the runtime) and never replaces itself: the ranks are children and
-    their exit status is ours."""
-    import socket
+    one rank per GPU.  This process never touches HIP (the GPUs are counted from the KFD
+    topology in sysfs) and never replaces itself: the ranks are children and their exit status
+    is ours.  ``--standalone`` lets the launcher pick its own rendezvous port (no probed port
+    that could be taken between the probe and the bind)."""
     import subprocess
 
-    visible = torch.cuda.device_count()
+    visible = visible_gpus()
     if visible < args.gpus:
         print(f"bench.py: --gpus {args.gpus} but only {visible} HIP device(s) visible; "
               "refusing to report a smaller world as if it were the requested one",
               file=sys.stderr)
         raise SystemExit(3)
-    with socket.socket() as probe:
-        probe.bind(("127.0.0.1", 0))
-        port = probe.getsockname()[1]
     passed = [a for a in sys.argv[1:] if a != "--spawn"]
-    command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-               f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-               "--master-port", str(port), str(Path(__file__).resolve()), *passed]
+    command = [sys.executable, "-m", "torch.distributed.run", "--standalone",
+               "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               str(Path(__file__).resolve()), *passed]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes
     done = subprocess.run(command, env=env, stdout=subprocess.PIPE, text=True)
@@ -133,8 +153,8 @@ def launch_ranks(args: argparse.Namespace) -> "NoReturn":
     raise SystemExit(done.returncode)
 
 
-KERNEL_SOURCES = ("ginfinity_amd/csrc/gine_layer.inc", "ginfinity_amd/csrc/gine_f16.hip",
-                  "ginfinity_amd/csrc/gfy_common.h")
+KERNEL_SOURCES = ("ginfinity_amd/csrc/gine_layer.inc", "ginfinity_amd/csrc/gine_layer_q.inc",
+                  "ginfinity_amd/csrc/gine_f16.hip", "ginfinity_amd/csrc/gfy_common.h")
 
 
 def kernel_source_sha16() -> str:
@@ -146,18 +166,20 @@ def kernel_source_sha16() -> str:
     return digest.hexdigest()[:16]
 
 
-def measured_traffic(kernel: str):
+def measured_traffic(kernel: str, nodes_per_launch: int):
     """HBM bytes per launch of ``kernel`` from the committed PMC passes (rocprofv3
     FETCH_SIZE / WRITE_SIZE, gfx950 half-count correction applied; tools/profile_round.sh +
-    tools/pmc_summary.py).  Counter passes cannot run inside this script, so the figure is
-    only reported while the summary was taken from the kernel source as it is now."""
+    tools/pmc_summary.py), scaled from the node count the passes ran on to this run's.  Counter
+    passes cannot run inside this script, so the figure is only reported while the summary was
+    taken from the kernel source as it is now."""
     newest = sorted((ROOT / "profiles").glob("r*_traffic_pmc.json"))
     for path in reversed(newest):
         try:
             summary = json.loads(path.read_text())
             if summary.get("kernel_source_sha16") != kernel_source_sha16():
                 continue
-            return summary["kernels"][kernel]["hbm_bytes_per_launch"]
+            measured = summary["kernels"][kernel]["hbm_bytes_per_launch"]
+            return measured * nodes_per_launch / summary.get("nodes_per_launch", NODES)
         except (OSError, KeyError, ValueError):
             continue
     return None
@@ -217,22 +239,33 @@ def distance_leg(rows: int, device) -> dict:
                          "kernel": "k_pairwise"}}
 
 
-def cross_shard(args, rank: int, local_rank: int, world: int, distributed: bool) -> None:
+def cross_shard(args, rank: int, local_rank: int, world: int, distributed: bool, *,
+                device=None, encode_block=None, search=None, make_shard=None) -> dict | None:
     """BASELINE configs[4] at a size that fits the run: every rank encodes its shards (no
     collective), the fp16 blocks are exchanged chunk by chunk (all_gather_into_tensor: RCCL
     over xGMI) while the chunks already there are searched, every rank keeps the nearest
-    other row of ITS rows over all ranks' rows.  Parity unpinned."""
+    other row of ITS rows over all ranks' rows.  Parity unpinned.
+
+    ``device`` / ``encode_block`` / ``search`` / ``make_shard`` replace the GPU pieces (tests:
+    the driver logic — shard ownership, fences, MAX-reductions, offsets, the result line — runs
+    under gloo on CPU tensors with the oracle as the search)."""
     import torch.distributed as dist
-    from ginfinity_amd import Ginfinity, parallel, synthetic
-    device = torch.device("cuda", local_rank)
-    encoder = Ginfinity.load(f"cuda:{local_rank}", allow_nondeterministic_cuda=True)
+    from ginfinity_amd import parallel, synthetic
+    on_gpu = device is None
+    if on_gpu:
+        from ginfinity_amd import Ginfinity
+        device = torch.device("cuda", local_rank)
+        encoder = Ginfinity.load(f"cuda:{local_rank}", allow_nondeterministic_cuda=True)
+        encode_block = lambda shard: encoder.encode_graphs_device(shard)[0]
+    make_shard = make_shard or synthetic.roofline_shard
     owned = parallel.shard_assignment(args.shards, world, rank)
-    shards = {s: synthetic.roofline_shard(s) for s in owned}
+    shards = {s: make_shard(s) for s in owned}
 
     def fence():
         if distributed:
             dist.barrier()
-        torch.cuda.synchronize(device)
+        if on_gpu:
+            torch.cuda.synchronize(device)
 
     def longest(seconds: float) -> float:
         if not distributed:
@@ -241,24 +274,27 @@ def cross_shard(args, rank: int, local_rank: int, world: int, distributed: bool)
         dist.all_reduce(worst, op=dist.ReduceOp.MAX)
         return float(worst.item())
 
-    encoder.encode_graphs_device(next(iter(shards.values())) if shards else synthetic.roofline_shard(0))
+    encode_block(next(iter(shards.values())) if shards else make_shard(0))     # warm
     fence()
     t0 = time.perf_counter()
-    blocks = [encoder.encode_graphs_device(shards[s])[0] for s in owned]
+    blocks = [encode_block(shards[s]) for s in owned]
     block = (torch.cat(blocks) if blocks else
              torch.empty((0, 128), dtype=torch.float16, device=device))
-    torch.cuda.synchronize(device)
+    if on_gpu:
+        torch.cuda.synchronize(device)
     encode_s = longest(time.perf_counter() - t0)
     fence()
     t1 = time.perf_counter()
-    values, indices, offsets = parallel.cross_shard_nearest(block, metric="cosine",
-                                                            chunk_rows=args.chunk_rows)
-    torch.cuda.synchronize(device)
+    values, indices, offsets = parallel.cross_shard_nearest(
+        block, metric="cosine", chunk_rows=args.chunk_rows, search=search)
+    if on_gpu:
+        torch.cuda.synchronize(device)
     search_s = longest(time.perf_counter() - t1)
     total = offsets[-1]
+    line = None
     if rank == 0:
         gathered_bytes = total * 128 * 2 * max(world - 1, 0)      # received by all ranks
-        print(json.dumps({
+        line = {
             "metric": "cross-shard nearest over sharded embeddings (BASELINE configs[4] in "
                       "miniature)", "value": float(total) * total / search_s,
             "unit": "pairs/s", "n_gpus": world, "higher_is_better": True, "scaling": "strong",
@@ -266,14 +302,16 @@ def cross_shard(args, rank: int, local_rank: int, world: int, distributed: bool)
             "config": {"workload": f"{args.shards} synthetic 60k-node shards over {world} GPU(s): "
                                    "shard-parallel encode, chunked all-gather, nearest other row "
                                    "(cosine) of every row", "rows_total": total,
-                       "chunk_rows": args.chunk_rows,
+                       "chunk_rows": args.chunk_rows, "rank_offsets": offsets,
                        "rccl_ranks": dist.get_world_size() if distributed else 0},
             "encode": {"seconds": encode_s, "nodes_per_s": total / encode_s,
                        "note": "numpy shards in, device blocks out (PCIe inclusive)"},
             "exchange_and_search": {"seconds": search_s,
                                     "bytes_received_all_ranks": gathered_bytes,
                                     "tflops": 2.0 * total * total * 128 / search_s / 1e12},
-            "sample": [float(values[0]), int(indices[0])] if values.numel() else None}))
+            "sample": [float(values[0]), int(indices[0])] if values.numel() else None}
+        print(json.dumps(line))
+    return line
 
 
 def main() -> None:
@@ -463,7 +501,7 @@ def main() -> None:
                      "`isolated` is the kernel by itself, `pipeline_frac` the whole step"
                      if lanes > 1 else "one batch at a time: the span is the kernel by itself"),
             **layer_roofline(timed_ms),
-            "traffic": measured_traffic(kernel_name),
+            "traffic": measured_traffic(kernel_name, full * NODES),
             "isolated": {"configuration": "one batch at a time, one HIP event pair around the "
                                           "plain layer launches",
                          **layer_roofline(sum(plain) / len(plain))},

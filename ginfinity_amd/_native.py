@@ -78,6 +78,8 @@ SIGNATURES: dict[str, tuple] = {
     "gfy_pairwise_nearest": (c_int, [c_void_p, c_int64, c_void_p, c_int64,
                                      c_int, c_int64, c_void_p, c_void_p,
                                      c_void_p, c_size_t, c_void_p]),
+    "gfy_pairwise_nearest_window": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64,
+                                            c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
 }
 
 

@@ -843,8 +843,23 @@ int gfy_pairwise_nearest(const void* a, int64_t n, const void* b, int64_t m,
               GFY_ERR_INVALID, "gfy_pairwise_nearest: bad arguments");
   GFY_REQUIRE(metric == GFY_L2 || metric == GFY_COSINE, GFY_ERR_INVALID,
               "gfy_pairwise_nearest: unknown metric %d", metric);
-  return launch_pairwise_nearest(a, n, b, m, metric, exclude_offset, best_val,
-                                 best_idx, ws, ws_bytes, (hipStream_t)stream);
+  return launch_pairwise_nearest(a, n, b, m, metric, exclude_offset, exclude_offset >= 0 ? 1 : 0,
+                                 best_val, best_idx, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int gfy_pairwise_nearest_window(const void* a, int64_t n, const void* b, int64_t m, int metric,
+                                int64_t window_first, float* best_val, int32_t* best_idx,
+                                void* ws, size_t ws_bytes, void* stream) {
+  clear_error();
+  GFY_REQUIRE(a && b && best_val && best_idx && ws && n > 0 && m > 0 && m < INT32_MAX,
+              GFY_ERR_INVALID, "gfy_pairwise_nearest_window: bad arguments");
+  GFY_REQUIRE(metric == GFY_L2 || metric == GFY_COSINE, GFY_ERR_INVALID,
+              "gfy_pairwise_nearest_window: unknown metric %d", metric);
+  GFY_REQUIRE(window_first >= 0 && window_first + m <= n, GFY_ERR_INVALID,
+              "gfy_pairwise_nearest_window: b must be rows [%lld, %lld) of the %lld rows of a",
+              (long long)window_first, (long long)(window_first + m), (long long)n);
+  return launch_pairwise_nearest(a, n, b, m, metric, -window_first, 1, best_val, best_idx, ws,
+                                 ws_bytes, (hipStream_t)stream);
 }
 
 }  // extern "C"

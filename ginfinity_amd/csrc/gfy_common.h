@@ -286,7 +286,7 @@ int launch_pairwise_dense(const void* a, int64_t n, const void* b, int64_t m,
                           int metric, float* out, void* ws, size_t ws_bytes,
                           hipStream_t s);
 int launch_pairwise_nearest(const void* a, int64_t n, const void* b, int64_t m,
-                            int metric, int64_t exclude_offset, float* best_val,
+                            int metric, int64_t exclude_offset, int exclude_on, float* best_val,
                             int32_t* best_idx, void* ws, size_t ws_bytes,
                             hipStream_t s);
 size_t pairwise_workspace_bytes(int64_t n, int64_t m);

@@ -79,7 +79,8 @@ struct PairArgs {
   const float* a_term;  // [n]
   int64_t n, m;
   int metric;
-  int64_t exclude_offset;
+  int64_t exclude_offset;   // with exclude_on: the pair (i, i + exclude_offset) is skipped (any sign)
+  int exclude_on;
   int blocks_a, chunks;
   int64_t chunk_rows;   // multiple of kTileB
   float* part_val;      // [chunks][n]   (nearest)
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_pairwise(const PairArgs p) {
     } else {
       // does this tile contain an excluded (i, i + offset) pair of this block?
       const int64_t ex_lo = a0 + p.exclude_offset, ex_hi = ex_lo + kBlockA;
-      const bool may_exclude = p.exclude_offset >= 0 && ex_lo < j0 + kTileB && ex_hi > j0;
+      const bool may_exclude = p.exclude_on && ex_lo < j0 + kTileB && ex_hi > j0;
       __builtin_amdgcn_sched_barrier(0);
       // The contraction is only 128 deep, so an epilogue of fma + compare + two selects
       // per element costs more vector cycles than the MFMAs that produced it.  Instead:
@@ -445,7 +446,7 @@ static int opt_in_pairwise_lds() {
 }
 
 int launch_pairwise_nearest(const void* a, int64_t n, const void* b, int64_t m,
-                            int metric, int64_t exclude_offset, float* best_val,
+                            int metric, int64_t exclude_offset, int exclude_on, float* best_val,
                             int32_t* best_idx, void* ws, size_t ws_bytes,
                             hipStream_t s) {
   const PairWorkspace w = carve(ws, n, m);
@@ -466,6 +467,7 @@ int launch_pairwise_nearest(const void* a, int64_t n, const void* b, int64_t m,
   p.m = m;
   p.metric = metric;
   p.exclude_offset = exclude_offset;
+  p.exclude_on = exclude_on;
   p.blocks_a = w.blocks_a;
   p.chunks = w.chunks;
   p.chunk_rows = w.chunk_rows;
@@ -502,7 +504,8 @@ int launch_pairwise_dense(const void* a, int64_t n, const void* b, int64_t m,
   p.n = n;
   p.m = m;
   p.metric = metric;
-  p.exclude_offset = -1;
+  p.exclude_offset = 0;
+  p.exclude_on = 0;
   p.blocks_a = (int)((n + kBlockA - 1) / kBlockA);
   p.chunks = 1;
   p.chunk_rows = (m + kTileB - 1) / kTileB * kTileB;

@@ -99,23 +99,14 @@ def all_gather_rows(block: torch.Tensor, group=None
 
 
 def _search_block(search, local: torch.Tensor, other: torch.Tensor, metric: str,
-                  own_first: int | None) -> tuple[torch.Tensor, torch.Tensor]:
-    """``search(local, other)`` with the pair (own_first + j, j) excluded for every row j of
-    ``other`` when ``other`` is rows [own_first, own_first + len(other)) of ``local`` itself
-    (the library excludes (i, i + k) for k >= 0 only, so the rows in front of the window,
-    the window and the rows behind it are searched separately)."""
+                  own_first: int | None, workspace=None) -> tuple[torch.Tensor, torch.Tensor]:
+    """``search(local, other)``; when ``other`` is rows [own_first, own_first + len(other)) of
+    ``local`` itself, every row skips itself (``window_first``: one call for the rows in front
+    of the window, inside it and behind it)."""
+    extra = {} if workspace is None else {"workspace": workspace}
     if own_first is None:
-        return search(local, other, metric=metric)
-    stop = own_first + int(other.shape[0])
-    values = torch.empty(local.shape[0], dtype=torch.float32, device=local.device)
-    indices = torch.empty(local.shape[0], dtype=torch.int32, device=local.device)
-    for lo, hi, exclude in ((0, own_first, None), (own_first, stop, 0),
-                            (stop, int(local.shape[0]), None)):
-        if hi > lo:
-            part = (search(local[lo:hi], other, metric=metric) if exclude is None else
-                    search(local[lo:hi], other, metric=metric, exclude_offset=exclude))
-            values[lo:hi], indices[lo:hi] = part
-    return values, indices
+        return search(local, other, metric=metric, **extra)
+    return search(local, other, metric=metric, window_first=own_first, **extra)
 
 
 def cross_shard_nearest(block: torch.Tensor, *, metric: str = "l2", group=None,
@@ -135,9 +126,11 @@ def cross_shard_nearest(block: torch.Tensor, *, metric: str = "l2", group=None,
 
     Returns (values float32 [rows_r], global row indices int64 [rows_r], rank offsets W+1).
     ``search`` (tests) replaces ``distance.nearest``."""
+    workspace = None
     if search is None:
         from . import distance
         search = distance.nearest
+        workspace = distance.NearestWorkspace()     # one set of buffers for every piece
     if metric not in ("l2", "cosine"):
         raise ValueError("metric must be 'l2' or 'cosine'")
     rank, size = world(group)
@@ -189,7 +182,7 @@ def cross_shard_nearest(block: torch.Tensor, *, metric: str = "l2", group=None,
             piece = (staging[chunk % len(staging)][other, :valid] if size > 1
                      else block[first:first + valid])
             values, indices = _search_block(search, block, piece, metric,
-                                            first if other == rank else None)
+                                            first if other == rank else None, workspace)
             indices = indices.to(torch.int64) + (offsets[other] + first)
             better = (values < best_value) if metric == "l2" else (values > best_value)
             better |= (values == best_value) & (indices < best_index)

@@ -46,7 +46,14 @@ def _map_tensors(path: Path) -> tuple[dict[str, str], dict[str, np.ndarray]]:
     header with dtype / shape / data_offsets per tensor, then the byte buffer).  Pages come in
     from the page cache when a micro-batch's slice is copied into the pinned upload buffer —
     the only host copy between the file and the device (``safetensors.numpy.load_file`` reads
-    the whole payload into fresh arrays first)."""
+    the whole payload into fresh arrays first).
+
+    Lifetime: the arrays are READ-ONLY views of the mapping, which lives as long as any of them
+    (numpy keeps the memmap referenced).  Replacing the file through ``save_graph_shard`` —
+    or any writer that renames a new file over the path, as the reference's does
+    (graph.py:770-791) — leaves a live mapping on the old inode untouched; truncating or
+    rewriting the file IN PLACE while a shard loaded from it is alive is undefined (SIGBUS),
+    as for any memory-mapped file."""
     size = path.stat().st_size
     with path.open("rb") as handle:
         prefix = handle.read(8)
@@ -63,6 +70,7 @@ def _map_tensors(path: Path) -> tuple[dict[str, str], dict[str, np.ndarray]]:
                         shape=(size - 8 - header_bytes,)) if size > 8 + header_bytes else \
         np.zeros(0, np.uint8)
     arrays = {}
+    spans: list[tuple[int, int, str]] = []
     for name, entry in header.items():
         dtype = np.dtype(_SAFETENSORS_DTYPES[entry["dtype"]])
         shape = tuple(int(d) for d in entry["shape"])
@@ -72,6 +80,16 @@ def _map_tensors(path: Path) -> tuple[dict[str, str], dict[str, np.ndarray]]:
             raise ValueError(f"tensor {name!r}: data offsets do not match dtype and shape")
         arrays[name] = np.frombuffer(payload, dtype=dtype, count=count,
                                      offset=begin).reshape(shape)
+        spans.append((begin, end, name))
+    # what safetensors itself checks on load: the tensors tile the byte buffer — no overlap, no
+    # hole, nothing behind the last one
+    position = 0
+    for begin, end, name in sorted(spans):
+        if begin != position:
+            raise ValueError(f"tensor {name!r}: byte ranges overlap or leave a gap")
+        position = end
+    if position != payload.shape[0]:
+        raise ValueError("safetensors file has trailing bytes behind its last tensor")
     return metadata, arrays
 
 

@@ -293,6 +293,14 @@ int gfy_pairwise_nearest(const void* a, int64_t n, const void* b, int64_t m,
                          int32_t* best_idx, void* workspace,
                          size_t workspace_bytes, void* stream);
 
+/* The same when b IS the rows [window_first, window_first + m) of a (one rank's own piece in
+ * the chunked cross-shard search): every a-row skips itself, i.e. the pair (window_first + j, j)
+ * is excluded for every j — rows in front of the window, inside it and behind it in ONE call. */
+int gfy_pairwise_nearest_window(const void* a, int64_t n, const void* b, int64_t m,
+                                int metric, int64_t window_first, float* best_val,
+                                int32_t* best_idx, void* workspace, size_t workspace_bytes,
+                                void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -197,3 +197,33 @@ def test_config4_one_million_rows_sampled_against_the_float64_oracle(metric):
         np.testing.assert_allclose(values[block], picked, atol=tolerance)
         worst = max(worst, float(np.abs(values[block] - best).max()))
     print(f"config 4 ({metric}): {sample.size} sampled rows, max |value - oracle| = {worst:.2e}")
+
+
+def test_nearest_window_skips_every_row_s_own_copy():
+    """``window_first``: b is rows [k, k + m) of a (one rank's own piece in the chunked
+    cross-shard search): one call must equal the float64 definition with the pairs (k + j, j)
+    removed — rows in front of the window, inside it, behind it; any alignment of the window
+    against the kernel's 256-row blocks and 128-row tiles."""
+    from ginfinity_amd import distance, synthetic
+    from oracle import gine_numpy as G
+    rows = synthetic.unit_rows(5, 3_000)
+    a = torch.from_numpy(rows).cuda()
+    workspace = distance.NearestWorkspace()
+    for first, count in ((0, 3_000), (0, 700), (129, 1_000), (2_300, 700), (1_111, 1), (511, 513)):
+        for metric in ("l2", "cosine"):
+            values, indices = distance.nearest(a, a[first:first + count], metric=metric,
+                                               window_first=first, workspace=workspace)
+            values, indices = values.cpu().numpy(), indices.cpu().numpy()
+            full = (G.pairwise_l2(rows, rows[first:first + count]) if metric == "l2"
+                    else G.pairwise_cosine(rows, rows[first:first + count]))
+            for j in range(count):
+                full[first + j, j] = np.inf if metric == "l2" else -np.inf
+            want = full.argmin(axis=1) if metric == "l2" else full.argmax(axis=1)
+            best = full[np.arange(rows.shape[0]), want]
+            chosen = full[np.arange(rows.shape[0]), indices]
+            assert not np.any(indices == np.arange(rows.shape[0]) - first)   # never itself
+            assert np.allclose(chosen, best, atol=2e-3), (first, count, metric)
+            assert np.allclose(values if metric == "cosine" else values ** 2,
+                               best if metric == "cosine" else best ** 2, atol=4e-3)
+    with pytest.raises(ValueError, match="rows"):
+        distance.nearest(a[:100], a[:200], window_first=0)

@@ -83,15 +83,17 @@ def test_shard_assignment_is_a_partition():
 # ---- chunked, overlapped cross-shard search (the collective + merge logic; the kernel behind
 # ---- `search` is covered by the single-GPU tests) ------------------------------------------
 
-def _oracle_search(a, b, *, metric="l2", exclude_offset=None):
+def _oracle_search(a, b, *, metric="l2", exclude_offset=None, window_first=None):
     """float64 definition (oracle/gine_numpy.py) with the library's signature: test stand-in
     for distance.nearest on CPU tensors."""
     from oracle import gine_numpy as G
     an, bn = a.numpy(), b.numpy()
     full = G.pairwise_l2(an, bn) if metric == "l2" else G.pairwise_cosine(an, bn)
-    if exclude_offset is not None and exclude_offset >= 0:
+    if window_first is not None:           # b = rows [window_first, ...) of a: skip (k + j, j)
+        exclude_offset = -int(window_first)
+    if exclude_offset is not None and (exclude_offset >= 0 or window_first is not None):
         for i in range(an.shape[0]):
-            if i + exclude_offset < bn.shape[0]:
+            if 0 <= i + exclude_offset < bn.shape[0]:
                 full[i, i + exclude_offset] = np.inf if metric == "l2" else -np.inf
     index = full.argmin(axis=1) if metric == "l2" else full.argmax(axis=1)
     value = full[np.arange(an.shape[0]), index] if an.shape[0] else np.zeros(0)
@@ -152,3 +154,59 @@ def test_cross_shard_nearest_world_size_one_needs_no_process_group():
     assert offsets == [0, 13]
     np.testing.assert_array_equal(indices.numpy(), direct_i.numpy().astype(np.int64))
     np.testing.assert_allclose(values.numpy(), direct_v.numpy())
+
+
+# ---- bench.py --workload cross-shard: the DRIVER logic under gloo, GPU pieces stubbed ----------
+
+def _bench_cross_shard_worker(rank: int, size: int, port: int, shards: int, queue) -> None:
+    import argparse
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    if str(root) not in sys.path:
+        sys.path.insert(0, str(root))
+    import bench
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    try:
+        args = argparse.Namespace(shards=shards, chunk_rows=5)
+        # shard s = 4 + s rows, every row recognisably its shard's; "encoding" returns them
+        make_shard = lambda s: _rows(100 + s, 4 + s)
+        line = bench.cross_shard(args, rank, rank, size, True, device=torch.device("cpu"),
+                                 encode_block=lambda shard: shard, search=_oracle_search,
+                                 make_shard=make_shard)
+        queue.put((rank, line))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_cross_shard_driver_logic_world_size_two():
+    """bench.py's cross-shard workload with the encoder and the matrix-core search replaced by
+    CPU stand-ins: shard s goes to rank s mod W, rank 0 prints ONE line whose totals and rank
+    offsets describe all ranks' rows, and the sample it reports is the true nearest other row."""
+    from oracle import gine_numpy as G
+    size, shards = 2, 5
+    context = mp.get_context("spawn")
+    queue = context.Queue()
+    port = _free_port()
+    procs = [context.Process(target=_bench_cross_shard_worker, args=(r, size, port, shards, queue))
+             for r in range(size)]
+    for p in procs:
+        p.start()
+    results = dict(queue.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results[1] is None and results[0] is not None           # one line, from rank 0
+    line = results[0]
+    per_rank = [sum(4 + s for s in range(shards) if s % size == r) for r in range(size)]
+    assert line["config"]["rows_total"] == sum(per_rank)
+    assert line["config"]["rank_offsets"] == [0, per_rank[0], per_rank[0] + per_rank[1]]
+    assert line["n_gpus"] == size and line["config"]["rccl_ranks"] == size
+    assert line["unit"] == "pairs/s" and line["value"] > 0
+    everything = np.concatenate(
+        [_rows(100 + s, 4 + s).numpy() for r in range(size) for s in range(shards) if s % size == r])
+    full = G.pairwise_cosine(everything, everything)
+    np.fill_diagonal(full, -np.inf)
+    assert line["sample"][1] == int(full[0].argmax())
+    assert abs(line["sample"][0] - full[0].max()) < 1e-6

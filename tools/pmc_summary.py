@@ -10,7 +10,7 @@ import re
 import sys
 from pathlib import Path
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = Path(__file__).resolve().parent.parent
 src = root / "gpurun_out" / tag
 sys.path.insert(0, str(root))
@@ -44,8 +44,10 @@ for kernel, c in traffic.items():
         c["hbm_bytes_per_launch"] = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
 json.dump({
     "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc TCC_* (three separate passes, "
-           "--kernel-trace only) -- ./tools/gfy_bench 60000 20 (tools/profile_round.sh); mean per "
-           "dispatch; workload = 60,000-node / 300,000-edge synthetic shard",
+           "--kernel-trace only) -- ./tools/gfy_bench 240000 20 (tools/profile_round.sh); mean per "
+           "dispatch; workload = 240,000 nodes / 1,200,000 edges in one launch sequence = four "
+           "60,000-node shards' worth (what a batch of 4 launches)",
+    "nodes_per_launch": 240000,
     "units": "FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them",
     "kernel_source_sha16": kernel_source_sha16(),
     "correction": "gfx950: FETCH_SIZE reports half the bytes of wide (16 B/lane) coalesced reads "
@@ -59,7 +61,7 @@ for sub in ("sq_a", "sq_b"):
         for kernel, counters in means(path).items():
             sq[kernel].update(counters)
 json.dump({
-    "how": "two rocprofv3 --pmc passes of 8 SQ counters over ./tools/gfy_bench 60000 20; mean per "
+    "how": "two rocprofv3 --pmc passes of 8 SQ counters over ./tools/gfy_bench 240000 20; mean per "
            "dispatch, summed over the chip (SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count "
            "quad-cycles per wave, SQ_VALU_MFMA_BUSY_CYCLES and SQ_LDS_* count cycles)",
     "kernels": sq}, open(root / "profiles" / f"{tag}_layer_sq_pmc.json", "w"), indent=1)

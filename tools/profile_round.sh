@@ -5,38 +5,46 @@
 # Writes gpurun_out/<tag>/…; `python tools/pmc_summary.py <tag>` condenses the counter passes
 # and the summaries judged are then copied into profiles/ (see profiles/README.md).
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 
-# 1. bench lines (default = 4 shards in flight; one shard at a time)
-timeout -k 10 400 python3 $R/bench.py --steps 1000 --warmup 100 > $OUT/bench_line.json 2> $OUT/bench_line.err || exit 1
-timeout -k 10 200 python3 $R/bench.py --steps 1000 --warmup 100 --streams 1 --no-cpu-baseline --distance-rows 0 > $OUT/bench_1stream_line.json 2>> $OUT/bench_line.err || exit 1
+# 1. bench lines: the default (batches of 4 shards, 2 in flight), one batch at a time, and one
+#    SHARD at a time (single-round launches: the round-2 kernel with the fused head)
+timeout -k 10 400 python3 $R/bench.py --steps 960 --warmup 96 > $OUT/bench_line.json 2> $OUT/bench_line.err || exit 1
+timeout -k 10 200 python3 $R/bench.py --steps 960 --warmup 96 --streams 1 --no-cpu-baseline --distance-rows 0 > $OUT/bench_1stream_line.json 2>> $OUT/bench_line.err || exit 1
+timeout -k 10 200 python3 $R/bench.py --steps 960 --warmup 96 --streams 1 --batch 1 --no-cpu-baseline --distance-rows 0 > $OUT/bench_single_line.json 2>> $OUT/bench_line.err || exit 1
+# ... and what the driver runs (20 steps, 5 warm-up): the repeated leg covers >= 10 ms
+timeout -k 10 200 python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --distance-rows 0 > $OUT/bench_driver_line.json 2>> $OUT/bench_line.err || exit 1
 
-# 2. per-kernel durations of the same command (kernel trace + stats only)
-for S in 1 4; do
+# 2. per-kernel durations of the same commands (kernel trace + stats only)
+for S in 1 2; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/kt$S -o kt --output-format csv -- \
-    python3 $R/bench.py --steps 1000 --warmup 100 --streams $S --no-cpu-baseline --distance-rows 0 > $OUT/bench_${S}stream_line_profiled.json 2> $OUT/kt$S.err || exit 1
+    python3 $R/bench.py --steps 960 --warmup 96 --streams $S --no-cpu-baseline --distance-rows 0 > $OUT/bench_${S}stream_line_profiled.json 2> $OUT/kt$S.err || exit 1
 done
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/kt_single -o kt --output-format csv -- \
+  python3 $R/bench.py --steps 960 --warmup 96 --streams 1 --batch 1 --no-cpu-baseline --distance-rows 0 > $OUT/bench_single_line_profiled.json 2> $OUT/kt_single.err || exit 1
 
-# 3. HBM traffic counters: separate passes, kernel trace only (MI355X_MICROARCH.md, HBM section)
+# 3. HBM traffic counters: separate passes, kernel trace only (MI355X_MICROARCH.md, HBM section).
+#    240,000 nodes in one graph = four shards' worth: the launches a batch of 4 makes
 for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"; do
   N=$(echo $C | cut -d' ' -f1)
   GFY_BENCH_STREAMS=1 timeout -k 10 200 rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$N -o pmc --output-format csv -- \
-    $R/tools/gfy_bench 60000 20 > $OUT/pmc_$N.log 2>&1 || exit 1
+    $R/tools/gfy_bench 240000 20 > $OUT/pmc_$N.log 2>&1 || exit 1
 done
 
 # 4. SQ counters of the layer kernel (two passes of 8)
 GFY_BENCH_STREAMS=1 timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS \
-  --kernel-trace -d $OUT/sq_a -o sq --output-format csv -- $R/tools/gfy_bench 60000 20 > $OUT/sq_a.log 2>&1 || exit 1
+  --kernel-trace -d $OUT/sq_a -o sq --output-format csv -- $R/tools/gfy_bench 240000 20 > $OUT/sq_a.log 2>&1 || exit 1
 GFY_BENCH_STREAMS=1 timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM SQ_INSTS_MFMA \
-  --kernel-trace -d $OUT/sq_b -o sq --output-format csv -- $R/tools/gfy_bench 60000 20 > $OUT/sq_b.log 2>&1 || exit 1
+  --kernel-trace -d $OUT/sq_b -o sq --output-format csv -- $R/tools/gfy_bench 240000 20 > $OUT/sq_b.log 2>&1 || exit 1
 
 # 5. C++ driver (no Python in the loop) and in-kernel phase stamps (diagnostic build)
-timeout -k 10 100 $R/tools/gfy_bench 60000 200 > $OUT/gfy_bench.txt 2>&1 || exit 1
-GFY_BENCH_STREAMS=1 timeout -k 10 100 $R/tools/gfy_bench_stamps 60000 50 > $OUT/gfy_bench_stamps.txt 2>&1 || exit 1
+timeout -k 10 100 $R/tools/gfy_bench 240000 200 > $OUT/gfy_bench.txt 2>&1 || exit 1
+GFY_BENCH_STREAMS=1 timeout -k 10 100 $R/tools/gfy_bench_stamps 240000 50 > $OUT/gfy_bench_stamps.txt 2>&1 || exit 1
+GFY_BENCH_STREAMS=1 timeout -k 10 100 $R/tools/gfy_bench_stamps 60000 50 > $OUT/gfy_bench_stamps_60k.txt 2>&1 || exit 1
 
 # 6. all-pairs distance (config 4): kernel durations and traffic of k_pairwise
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/kt_pairwise -o kt --output-format csv -- \
