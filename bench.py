@@ -441,12 +441,12 @@ def main() -> None:
                     "mfma_tflops": launch_flops / (layer_ms * 1e-3) / 1e12,
                     "mfma_frac": launch_flops / (layer_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS}
 
-        # marks: setup | layer 1 .. layer L | head.  One-round launches (batch 1) run the head
-        # inside the last layer's launch, which is then left out of the mean; persistent-rounds
-        # launches (a batch) run it as its own kernel and all L layer launches are alike.
-        fused_head = full * NODES <= 256 * 8 * 32
+        # marks: setup | layer 1 .. layer L | stand-alone head (0 for fp16 output: the last
+        # layer's launch runs head + normalise too, in the one-round kernel and in the
+        # persistent-rounds kernel alike); layers 1 .. L-1 carry no head and are the ones
+        # the roofline figure is about
         def plain_layers(times: list[float]) -> list[float]:
-            return times[1:-2] if fused_head else times[1:-1]
+            return times[1:-2]
 
         # (1) the timed configuration: every lane busy.  With several streams in flight the
         # span between two HIP events of one stream contains the other streams' kernels, so
@@ -461,7 +461,7 @@ def main() -> None:
             torch.cuda.synchronize(device)
             for e in engines:
                 per_layer = e.kernel_times_ms()
-                samples += per_layer[:-1] if fused_head else per_layer
+                samples += per_layer[:-1]            # the last launch carries the head
         for e in engines:
             e.set_timing(False)
         timed_ms = sum(samples) / len(samples)
@@ -488,7 +488,8 @@ def main() -> None:
         torch.cuda.synchronize(device)
         alone_call_ms = e0.elapsed_time(e1) / rounds
         plain = plain_layers(mean)
-        kernel_name = "k_gine_layer_f16" if fused_head else "k_gine_layer_q"
+        one_round = full * NODES <= 256 * 8 * 32        # a CU gets at most one round of tiles
+        kernel_name = "k_gine_layer_f16" if one_round else "k_gine_layer_q"
         roofline = {
             "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "kernel": kernel_name, "shards_per_launch": full,
@@ -512,11 +513,10 @@ def main() -> None:
         }
         kernels = {"configuration": f"one batch of {full} shard(s) at a time on one stream "
                                     "(gfy_encode_coo_batch: k_csr_count, k_encode_setup_coo, "
-                                    "4 layer launches" + ("" if fused_head else ", k_head_d") + ")",
+                                    "4 layer launches, the last with head + normalise)",
                    "whole_call_ms": alone_call_ms, "per_shard_ms": alone_call_ms / full,
                    "csr_finish_plans_input_linear_ms": mean[0], "layer_ms": plain,
-                   ("last_layer_with_head_normalise_ms" if fused_head else "head_normalise_ms"):
-                       mean[-2] if fused_head else mean[-1]}
+                   "last_layer_with_head_normalise_ms": mean[-2]}
 
     distance = None
     if rank == 0 and world == 1 and args.distance_rows > 0:

@@ -448,9 +448,11 @@ int prepare_device_f16() {   // gfy_encoder_create, with the encoder's device cu
     GFY_OPT_IN((k_gine_layer_f16<false, false>), kLdsBytes);
     GFY_OPT_IN((k_gine_layer_f16<true, true>), kLdsBytes);
     GFY_OPT_IN((k_gine_layer_f16<false, true>), kLdsBytes);
-    GFY_OPT_IN((k_gine_layer_q<true>), kQLdsBytes);
-    GFY_OPT_IN((k_gine_layer_q<false>), kQLdsBytes);
-    GFY_OPT_IN((k_gine_layer_q<true, true>), kQLdsBytes);
+    GFY_OPT_IN((k_gine_layer_q<true, false, false>), kQLdsBytes);
+    GFY_OPT_IN((k_gine_layer_q<false, false, false>), kQLdsBytes);
+    GFY_OPT_IN((k_gine_layer_q<true, false, true>), kQLdsBytes);
+    GFY_OPT_IN((k_gine_layer_q<false, false, true>), kQLdsBytes);
+    GFY_OPT_IN((k_gine_layer_q<true, true, false>), kQLdsBytes);
     GFY_OPT_IN(k_head_d, kLdsBytes);
 #undef GFY_OPT_IN
     return GFY_OK;
@@ -529,13 +531,15 @@ static int encode_f16_on(const gfy_encoder* enc, const ShardTable& shards, const
   // fp16 output of a full encode: the round-2 kernel's last launch runs the head as well
   // (GFY_OPT_SEPARATE_HEAD keeps the stand-alone head kernel: A/B runs and parity tests)
   const bool fuse_head =
-      tap_stage < 0 && out_dtype == GFY_F16 && stop > 0 && !enc->separate_head && !persistent;
-  // rows the layer kernels may look up in row_ptr (the direct path of hub tiles): the caller's
-  // CSR has n + 1 entries, the one finished here covers the padded rows as well
-  const int csr_limit = coo ? (int)rows : shards.nodes[0];
+      tap_stage < 0 && out_dtype == GFY_F16 && stop > 0 && !enc->separate_head;
   const int32_t* const csr_rows = coo ? coo->row_ptr : row_ptr;
   const int32_t* const csr_col = coo ? coo->col : col;
   const uint8_t* const csr_typ = coo ? coo->typ : typ;
+  // rows the layer kernels may look up in row_ptr (the direct path of hub tiles): the caller's
+  // CSR has n + 1 entries, the one finished here covers the padded rows as well
+  const int csr_limit = coo ? (int)rows : shards.nodes[0];
+  HeadOut no_out{};
+  const HeadOut head_out{enc->f16.head, shards, normalise};
   for (int l = 0; l < stop; ++l) {
     int32_t* const spent = coo && l == 0 && coo->scan_free ? coo->scratch.tile_sum : nullptr;
     unsigned long long* const span = enc->timing == 3 ? enc->device_spans + 2 * l : nullptr;
@@ -544,19 +548,20 @@ static int encode_f16_on(const gfy_encoder* enc, const ShardTable& shards, const
   k_gine_layer_f16<RES, HEAD><<<layer_grid, kLThreads, kLdsBytes, s>>>(                      \
       enc->f16.layer[l], ha, hb, csr_rows, csr_col, csr_typ, plans, csr_limit, layer_tiles,  \
       enc->f16.head, shards, normalise, spent, span)
-    if (persistent && enc->residual)
-      k_gine_layer_q<true><<<p_grid, kLThreads, kQLdsBytes, s>>>(
-          enc->f16.layer[l], ha, hb, csr_rows, csr_col, csr_typ, plans, csr_limit, layer_tiles,
-          stagger, spent, span);
-    else if (persistent)
-      k_gine_layer_q<false><<<p_grid, kLThreads, kQLdsBytes, s>>>(
-          enc->f16.layer[l], ha, hb, csr_rows, csr_col, csr_typ, plans, csr_limit, layer_tiles,
-          stagger, spent, span);
+#define GFY_LAUNCH_ROUNDS(RES, HEAD)                                                         \
+  k_gine_layer_q<RES, false, HEAD><<<p_grid, kLThreads, kQLdsBytes, s>>>(                    \
+      enc->f16.layer[l], ha, hb, csr_rows, csr_col, csr_typ, plans, csr_limit, layer_tiles,  \
+      stagger, spent, span, kTapNone, nullptr, HEAD ? head_out : no_out)
+    if (persistent && enc->residual && with_head) GFY_LAUNCH_ROUNDS(true, true);
+    else if (persistent && enc->residual) GFY_LAUNCH_ROUNDS(true, false);
+    else if (persistent && with_head) GFY_LAUNCH_ROUNDS(false, true);
+    else if (persistent) GFY_LAUNCH_ROUNDS(false, false);
     else if (enc->residual && with_head) GFY_LAUNCH_LAYER(true, true);
     else if (enc->residual) GFY_LAUNCH_LAYER(true, false);
     else if (with_head) GFY_LAUNCH_LAYER(false, true);
     else GFY_LAUNCH_LAYER(false, false);
 #undef GFY_LAUNCH_LAYER
+#undef GFY_LAUNCH_ROUNDS
     f16* sw = ha;
     ha = hb;
     hb = sw;
@@ -698,9 +703,9 @@ int launch_debug_layer_f16(const gfy_encoder* enc, int layer, const void* hidden
   const int tiles_per_xcd = (layer_tiles + 7) / 8;
   const int wanted = (tiles_per_xcd + kLWaves - 1) / kLWaves, per_xcd = enc->cus / 8;
   const int grid = 8 * (wanted < per_xcd ? wanted : per_xcd);
-  k_gine_layer_q<true, true><<<grid, kLThreads, kQLdsBytes, s>>>(
+  k_gine_layer_q<true, true, false><<<grid, kLThreads, kQLdsBytes, s>>>(
       enc->f16.layer[layer], ha, hb, row_ptr, col, typ, plans, (int)n, layer_tiles, 0, nullptr,
-      nullptr, tap, taps);
+      nullptr, tap, taps, HeadOut{});
   if (tap == kTapNone) copy_rows(hb, (f16*)out, n * 8);
   else copy_rows(taps, (f16*)out, n * (tap == kTapV ? 16 : 8));   // stored -> natural order
   GFY_CHECK_HIP(hipGetLastError());
