@@ -81,6 +81,24 @@ def test_batch_of_synthetic_shards_matches_the_reference_rows(gpu_encoder, golde
         assert outs[seed].cpu().numpy().tobytes() == _single(engine, shards[seed]).tobytes()
 
 
+def test_stand_alone_head_behind_persistent_rounds_gives_the_same_bytes(gpu_encoder, mixed_shards):
+    """GFY_OPT_SEPARATE_HEAD: head + normalise as their own launch (k_head_d) behind the
+    persistent-rounds layers instead of inside the last of them — the same pipeline on the
+    same registers' worth of data, so the same bytes."""
+    engine = gpu_encoder._engine
+    inputs = [_device(engine, shard) for shard in mixed_shards]
+    try:
+        engine.set_option(native.GFY_OPT_LAYER_KERNEL, 3)
+        fused = [o.cpu().numpy() for o in engine.encode_coo_batch(inputs)]
+        engine.set_option(native.GFY_OPT_SEPARATE_HEAD, 1)
+        apart = [o.cpu().numpy() for o in engine.encode_coo_batch(inputs)]
+    finally:
+        engine.set_option(native.GFY_OPT_SEPARATE_HEAD, 0)
+        engine.set_option(native.GFY_OPT_LAYER_KERNEL, -1)
+    for a, b in zip(fused, apart):
+        assert a.tobytes() == b.tobytes()
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_batch_other_output_dtypes_equal_single(gpu_encoder, mixed_shards, dtype):
     engine = gpu_encoder._engine
