@@ -15,7 +15,12 @@ module.  Differences a user can observe, all deliberate:
   loaded for ``"cuda"`` never routes there, and nothing comes from ``oracle/``;
 * the per-record arrays returned by one call are views into one host block
   (C-contiguous, independent rows) instead of separate allocations, unless
-  ``encoder.independent_outputs = True``.
+  ``encoder.independent_outputs = True``;
+* ``load(..., pinned_outputs=True)`` (not in the reference; off by default): that one host
+  block is page-locked memory from torch's caching host allocator and the embeddings are
+  DMA'd straight into it — no staging copy on the host, the call runs at PCIe speed.  The
+  arrays are ordinary numpy views; the block returns to the allocator's cache when the last
+  of them is dropped.
 """
 from __future__ import annotations
 
@@ -71,8 +76,10 @@ def microbatch_bounds(lengths: Sequence[int], edge_counts: Sequence[int],
     total = len(lengths)
     if total == 0:
         return []
-    nodes = np.concatenate(([0], np.cumsum(np.asarray(lengths, dtype=np.int64))))
-    edges = np.concatenate(([0], np.cumsum(np.asarray(edge_counts, dtype=np.int64))))
+    nodes = np.zeros(total + 1, dtype=np.int64)
+    edges = np.zeros(total + 1, dtype=np.int64)
+    np.cumsum(lengths, out=nodes[1:])           # (ndarrays welcome: a 5,840-tuple costs
+    np.cumsum(edge_counts, out=edges[1:])       #  0.15 ms to convert)
     bounds: list[tuple[int, int]] = []
     start = 0
     while start < total:
@@ -154,6 +161,37 @@ class _Downloader:
         return finish(host)
 
 
+class _DirectDownloader:
+    """Device block → a row range of a PINNED host block, one DMA per micro-batch on one copy
+    stream, issued by the launching thread itself (an enqueue: no worker thread, no host
+    memcpy, nothing to contend for the GIL).  ``pinned_outputs`` only."""
+
+    class _Landed:
+        def __init__(self, event: "torch.cuda.Event") -> None:
+            self._event = event
+
+        def result(self) -> None:
+            self._event.synchronize()
+
+    def __init__(self, device: torch.device, streams: int = 1) -> None:
+        # (two streams taken in turn share the link: 0.42-0.45 ms per 15 MB copy instead of
+        # 0.31, same total — measured with tools/api_probe3.py)
+        self._streams = [torch.cuda.Stream(device=device) for _ in range(streams)]
+        self._turn = 0
+
+    def submit(self, block: torch.Tensor, ready: "torch.cuda.Event",
+               destination: torch.Tensor) -> "_DirectDownloader._Landed":
+        stream = self._streams[self._turn]
+        self._turn = (self._turn + 1) % len(self._streams)
+        stream.wait_event(ready)
+        with torch.cuda.stream(stream):
+            destination.copy_(block, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(stream)
+        block.record_stream(stream)                   # its memory is reused only after the DMA
+        return self._Landed(done)
+
+
 class _Uploader:
     """Several small host arrays → device tensors with ONE copy: they are packed into a
     pinned staging buffer (ring, each slot guarded by the event of its last copy) and go up
@@ -168,7 +206,7 @@ class _Uploader:
     _TORCH = {np.dtype(np.uint8): torch.uint8, np.dtype(np.int64): torch.int64,
               np.dtype(np.int32): torch.int32, np.dtype(np.float32): torch.float32}
 
-    def __init__(self, device: torch.device, slots: int = 6) -> None:
+    def __init__(self, device: torch.device, slots: int = 8) -> None:
         self._device = device
         self._staging: list[torch.Tensor | None] = [None] * slots
         self._copied: list["torch.cuda.Event | None"] = [None] * slots
@@ -210,7 +248,8 @@ class _Uploader:
                 else:
                     base, low, high = rebase
                     np.subtract(array, base, out=target)
-                    if int(target.min()) < low - base or int(target.max()) >= high - base:
+                    # one pass: as unsigned, a value below `low` wraps to ≥ 2^31 > high - low
+                    if target.size and int(target.view(np.uint32).max()) >= high - low:
                         raise GraphValidationError("edge index outside shard node range")
         return slot, arrays, offsets, total
 
@@ -246,6 +285,7 @@ class Ginfinity:
         self._engine = engine
         self._host = host
         self._copier: _Downloader | None = None
+        self._direct: _DirectDownloader | None = None
         self._preparer: ThreadPoolExecutor | None = None
         self._uploader: _Uploader | None = None
         self._metadata = checkpoint.metadata
@@ -258,14 +298,18 @@ class Ginfinity:
         #: micro-batch are row ranges of ONE host block (no per-record copy — keeping a single
         #: record alive keeps its block alive)
         self.independent_outputs = False
+        #: True: the host block of a call is page-locked memory (torch's caching host
+        #: allocator) and the device writes into it directly; see the module docstring
+        self.pinned_outputs = False
 
     @classmethod
     def load(cls, device: str = "cpu", *,
              allow_nondeterministic_cuda: bool = False,
              model_dir: str | Path | None = None,
-             full_precision: bool = False) -> "Ginfinity":
+             full_precision: bool = False,
+             pinned_outputs: bool = False) -> "Ginfinity":
         """Same signature, defaults and device policy as the reference
-        (src/ginfinity/api.py:64-76)."""
+        (src/ginfinity/api.py:64-76); ``pinned_outputs`` is this build's (module docstring)."""
         if not isinstance(device, str) or (device != "cpu" and not device.startswith("cuda")):
             raise ValueError("device must be 'cpu' or a CUDA device")
         if device.startswith("cuda"):
@@ -280,7 +324,9 @@ class Ginfinity:
         engine = DeviceEncoder(checkpoint.weight_pack,
                                full_precision=full_precision,
                                device=torch.device(device))
-        return cls(engine, checkpoint, device, full_precision=full_precision)
+        loaded = cls(engine, checkpoint, device, full_precision=full_precision)
+        loaded.pinned_outputs = bool(pinned_outputs)
+        return loaded
 
     # -- metadata -----------------------------------------------------------------
     @property
@@ -344,20 +390,17 @@ class Ginfinity:
         torch_dtype, _code, exact = device_output_dtype(embedding_dtype)
         engine, device = self._engine, self._engine.device
         spec = self._graph_spec
-        if self._copier is None:
-            self._copier = _Downloader(device)
         if self._uploader is None:
             self._uploader = _Uploader(device)
         pending, verdicts = [], []
         bounds = microbatch_bounds(lengths, edge_counts, max_batch_nodes, max_batch_edges)
         produced = np.dtype(embedding_dtype) if exact else np.dtype(np.float64)
-        host_block = np.empty((int(text.node_ptr[-1] - text.node_ptr[0]),
-                               self.embedding_dimension), dtype=produced)
-        _advise_huge_pages(host_block)
+        host_block, fetch = self._landing(int(text.node_ptr[-1] - text.node_ptr[0]), produced,
+                                          torch_dtype, exact)
         # the positional columns (numpy sin / cos, GIL released) of later micro-batches are
         # computed on a second helper thread while this one uploads and launches
         if self._preparer is None:
-            self._preparer = ThreadPoolExecutor(max_workers=3,
+            self._preparer = ThreadPoolExecutor(max_workers=6,
                                                 thread_name_prefix="ginfinity-prep")
         columns_of = [self._preparer.submit(text.positional, a, b) for a, b in bounds]
         for (start, stop), columns_job in zip(bounds, columns_of):
@@ -377,8 +420,7 @@ class Ginfinity:
             ready.record(torch.cuda.current_stream(device))
             verdicts.append((start, first_invalid))
             row = n0 - int(text.node_ptr[0])
-            pending.append((self._copier.submit(block, ready, lambda host: None,
-                                                host_block[row:row + n1 - n0]),
+            pending.append((fetch(block, ready, row, n1 - n0),
                             row, n1 - n0, lengths[start:stop]))
         outputs: list[np.ndarray] = []
         for job, row, kept, counts in pending:     # views cut here, as the copies land
@@ -413,9 +455,9 @@ class Ginfinity:
                 "this encoder")
         if max_batch_nodes <= 0 or max_batch_edges <= 0:
             raise ValueError("batch node and edge limits must be positive")
-        if max(shard.lengths) > max_batch_nodes:
+        if int(np.diff(shard.node_ptr).max()) > max_batch_nodes:
             raise ValueError("max_batch_nodes is smaller than the longest graph")
-        if max(shard.edge_counts) > max_batch_edges:
+        if int(np.diff(shard.edge_ptr).max()) > max_batch_edges:
             raise ValueError("max_batch_edges is smaller than the largest graph")
         return shard
 
@@ -429,7 +471,7 @@ class Ginfinity:
         if shard is None:
             return []
         embedding_dtype = _embedding_dtype(embedding_dtype)
-        bounds = microbatch_bounds(shard.lengths, shard.edge_counts,
+        bounds = microbatch_bounds(np.diff(shard.node_ptr), np.diff(shard.edge_ptr),
                                    max_batch_nodes, max_batch_edges)
         if len(bounds) == 1:
             return self._run_graph_shard(shard, embedding_dtype)
@@ -446,18 +488,15 @@ class Ginfinity:
         # call is bound by the 230 MB of D2H (config 2), not by a thread.  Compute stays on ONE
         # stream in micro-batch order (one encoder, one workspace).
         torch_dtype, _code, exact = device_output_dtype(embedding_dtype)
-        if self._copier is None:
-            self._copier = _Downloader(self._engine.device)
         if self._uploader is None:
             self._uploader = _Uploader(self._engine.device)
         if self._preparer is None:
-            self._preparer = ThreadPoolExecutor(max_workers=4,
+            self._preparer = ThreadPoolExecutor(max_workers=6,
                                                 thread_name_prefix="ginfinity-prep")
         uploader = self._uploader
-        core_counts = shard.core_counts
+        core_counts = shard.core_count_array()
         produced = np.dtype(embedding_dtype) if exact else np.dtype(np.float64)
-        host_block = np.empty((int(sum(core_counts)), self.embedding_dimension), dtype=produced)
-        _advise_huge_pages(host_block)
+        host_block, fetch = self._landing(int(core_counts.sum()), produced, torch_dtype, exact)
 
         def prepare(slot: int, start: int, stop: int):
             # the arrays of GraphShard.slice(start, stop) (graph.py:414-444: edge indices
@@ -498,9 +537,8 @@ class Ginfinity:
             # (the workers run no interpreter-level loops: a worker cutting 400 views holds the
             # GIL for 0.3 ms at a time and this thread, which needs it between every two
             # enqueues, took 0.6 ms per micro-batch instead of 0.1)
-            pending.append((self._copier.submit(
-                block, ready, lambda host: None, host_block[first_row:first_row + kept]),
-                first_row, kept, core_counts[start:stop]))
+            pending.append((fetch(block, ready, first_row, kept),
+                            first_row, kept, core_counts[start:stop]))
             first_row += kept
         # the per-record views are cut here, micro-batch by micro-batch as the copies land
         outputs: list[np.ndarray] = []
@@ -509,6 +547,27 @@ class Ginfinity:
             outputs.extend(self._splitter(counts, embedding_dtype, exact)(
                 host_block[row:row + kept]))
         return outputs
+
+    def _landing(self, rows: int, produced: np.dtype, torch_dtype: torch.dtype, exact: bool):
+        """The host block of one call and the function that brings a micro-batch's device
+        block into rows [first, first + count) of it: ``(host_block, fetch)``;
+        ``fetch(block, ready, first, count)`` returns an object whose ``result()`` waits for
+        the rows."""
+        width = self.embedding_dimension
+        if self.pinned_outputs and exact and not self.independent_outputs:
+            if self._direct is None:
+                self._direct = _DirectDownloader(self._engine.device)
+            landing = torch.empty((rows, width), dtype=torch_dtype, pin_memory=True)
+            direct = self._direct
+            return landing.numpy(), lambda block, ready, first, count: direct.submit(
+                block, ready, landing[first:first + count])
+        if self._copier is None:
+            self._copier = _Downloader(self._engine.device)
+        host_block = np.empty((rows, width), dtype=produced)
+        _advise_huge_pages(host_block)
+        copier = self._copier
+        return host_block, lambda block, ready, first, count: copier.submit(
+            block, ready, lambda host: None, host_block[first:first + count])
 
     def _splitter(self, core_counts, embedding_dtype: np.dtype, exact: bool):
         """host block → the per-record arrays of one micro-batch (views of the block, or

@@ -236,10 +236,15 @@ class GraphShard:
 
     @property
     def core_counts(self) -> tuple[int, ...]:
-        per_record = np.add.reduceat(
-            (self.node_roles == NODE_ROLE_CORE).astype(np.int64),
-            self.node_ptr[:-1])
-        return tuple(per_record.tolist())
+        return tuple(self.core_count_array().tolist())
+
+    def core_count_array(self) -> np.ndarray:
+        """int64 [records]: core nodes per record (== the lengths when no record has context
+        nodes, the usual case — one pass over ``node_roles`` finds that out)."""
+        if not self.node_roles.any():            # NODE_ROLE_CORE == 0
+            return np.diff(self.node_ptr).astype(np.int64)
+        return np.add.reduceat(self.node_roles == NODE_ROLE_CORE, self.node_ptr[:-1],
+                               dtype=np.int64)
 
     # -- construction -----------------------------------------------------------
     @classmethod

@@ -363,6 +363,37 @@ def test_independent_outputs_own_their_memory(gpu_encoder, rouskin_shard):
         gpu_encoder.independent_outputs = False
 
 
+def test_pinned_outputs_give_the_same_arrays(gpu_encoder, rouskin_shard, rouskin_records):
+    """``pinned_outputs``: the call's host block is page-locked and written by the device
+    directly (api._DirectDownloader) — same bytes, same shapes and dtypes, in
+    ``encode_graphs`` and ``encode_many``, for every output dtype; the arrays stay valid
+    after later calls have recycled the allocator's blocks."""
+    import gc
+    shard = rouskin_shard.slice(0, 600)
+    want = {dtype: gpu_encoder.encode_graphs(shard, max_batch_nodes=20_000, embedding_dtype=dtype)
+            for dtype in (np.float16, np.float32, np.float64)}
+    many = gpu_encoder.encode_many(rouskin_records[:300], max_batch_nodes=20_000)
+    gpu_encoder.pinned_outputs = True
+    try:
+        kept = {}
+        for dtype, expected in want.items():
+            got = gpu_encoder.encode_graphs(shard, max_batch_nodes=20_000, embedding_dtype=dtype)
+            assert len(got) == len(expected)
+            for a, b in zip(got, expected):
+                assert a.dtype == b.dtype and a.shape == b.shape and a.flags.c_contiguous
+                assert a.tobytes() == b.tobytes()
+            kept[dtype] = (got[7], expected[7].copy())
+            del got
+            gc.collect()                      # the block survives through the one kept view
+        got_many = gpu_encoder.encode_many(rouskin_records[:300], max_batch_nodes=20_000)
+        for a, b in zip(got_many, many):
+            assert a.tobytes() == b.tobytes()
+        for view, expected in kept.values():
+            np.testing.assert_array_equal(view, expected)
+    finally:
+        gpu_encoder.pinned_outputs = False
+
+
 # ---- full_precision (fp32 model) ------------------------------------------------------------
 
 def test_fp32_model_example8(gpu_encoder_fp32, golden):
