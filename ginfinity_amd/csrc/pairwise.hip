@@ -33,6 +33,17 @@ constexpr int kBlockA = 256;  // a-rows per workgroup
 constexpr int kTileB = 128;   // b-rows per LDS tile
 constexpr int kThreads = 512;
 constexpr int kBuffers = 4;   // b-tile ring: tile i is consumed while i+1 .. i+3 are in flight
+#ifndef GFY_PAIRWISE_TILES_PER_BARRIER
+#define GFY_PAIRWISE_TILES_PER_BARRIER 2   // nearest: 2 = a barrier per pair of tiles, 1 = per tile
+#endif
+
+template <class T>
+__device__ __forceinline__ const T* uniform_pointer(const T* pointer) {
+  const uint64_t bits = (uint64_t)(uintptr_t)pointer;
+  const uint32_t low = __builtin_amdgcn_readfirstlane((uint32_t)bits);
+  const uint32_t high = __builtin_amdgcn_readfirstlane((uint32_t)(bits >> 32));
+  return reinterpret_cast<const T*>(((uint64_t)high << 32) | low);
+}
 
 __device__ __forceinline__ int off256(int row, int chunk) {
   return row * 256 + ((chunk ^ (row & 15)) << 4);
@@ -40,8 +51,11 @@ __device__ __forceinline__ int off256(int row, int chunk) {
 
 // per-row (s, t) on the b side, (na or 1/|a|) on the a side
 // s/t are written for `padded` >= count rows: the rows past the end get key = +inf
+// fold (L2 nearest): t = -|b_j|^2 / 2 — the accumulators of k_pairwise<false, true> START from
+// it, so that what comes out of the MFMAs is already  g_ij = a_i.b_j - |b_j|^2 / 2  =  -key_ij / 2
+// (maximised; -2 g is exact); padding rows get -inf
 __global__ __launch_bounds__(256) void k_row_terms(const f16* __restrict__ rows, int64_t count,
-                                                   int64_t padded, int metric,
+                                                   int64_t padded, int metric, int fold,
                                                    float* __restrict__ s_out,
                                                    float* __restrict__ t_out,
                                                    float* __restrict__ a_term) {
@@ -61,13 +75,13 @@ __global__ __launch_bounds__(256) void k_row_terms(const f16* __restrict__ rows,
     const float inv = 1.0f / (nrm > 1e-12f ? nrm : 1e-12f);
     if (s_out) {
       s_out[row] = metric == GFY_L2 ? -2.0f : -inv;
-      t_out[row] = metric == GFY_L2 ? ss : 0.0f;
+      t_out[row] = metric == GFY_L2 ? (fold ? -0.5f * ss : ss) : 0.0f;
     }
     if (a_term) a_term[row] = metric == GFY_L2 ? ss : inv;
   }
   if (row >= count && row < padded && chunk == 0 && s_out) {
     s_out[row] = 0.f;
-    t_out[row] = __builtin_inff();   // never wins
+    t_out[row] = fold ? -__builtin_inff() : __builtin_inff();   // never wins
   }
 }
 
@@ -92,8 +106,11 @@ constexpr int kRowBytes = kTileB * 256;        // one b-tile of rows
 constexpr int kTermBytes = 2 * kTileB * 4;     // its (s, t)
 constexpr int kTermSlots = 4;                  // (s, t) ring, like the rows
 
-template <bool kDense>
+// kFold (nearest, L2): see k_row_terms — the epilogue is a running maximum of the accumulators
+// themselves: no per-element fma, no (s, t) operand reads per a-tile.
+template <bool kDense, bool kFold = false>
 __global__ __launch_bounds__(kThreads, 1) void k_pairwise(const PairArgs p) {
+  static_assert(!(kDense && kFold), "the folded form is the nearest-row epilogue's");
   extern __shared__ __attribute__((aligned(16))) char smem[];   // kBuffers buffers
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
@@ -120,10 +137,12 @@ __global__ __launch_bounds__(kThreads, 1) void k_pairwise(const PairArgs p) {
   // the DMA look-ahead.  The asm keeps hipcc from hoisting them out of the loop again.)
   // `home` is rebuilt from threadIdx.x per request (six VALU operations): any loop-invariant
   // register here is one that hipcc spills.
-  auto request = [&](int k) {   // tile k of this workgroup's sweep
+  auto request = [&](int k) __attribute__((always_inline)) {   // tile k of this workgroup's sweep
     const int64_t j0 = j_begin + (int64_t)k * kTileB;
     const uint32_t base = lds0 + (uint32_t)(k & (kBuffers - 1)) * kRowBytes;
-    const f16* rows = p.b + j0 * 128;   // wave-uniform
+    // wave-uniform, and said so: with the carried reduce below in the loop hipcc's divergence
+    // analysis puts j0 in vector registers, which the DMA's scalar base operand cannot take
+    const f16* rows = uniform_pointer(p.b + j0 * 128);
     uint32_t me = threadIdx.x;
     asm volatile("" : "+v"(me));
     const uint32_t sub = (me >> 4) & 3u, slot = me & 15u;
@@ -144,10 +163,10 @@ __global__ __launch_bounds__(kThreads, 1) void k_pairwise(const PairArgs p) {
               base + (uint32_t)(wave * 4 + q) * 1024u);
       }
     }
-    if (wave < 2 && (me & 32u) == 0)   // 128 floats = 32 lanes x 16 B
-      dma16((wave == 0 ? p.s : p.t) + j0, (me & 31u) * 16u,
+    if (wave < (kFold ? 1 : 2) && (me & 32u) == 0)   // 128 floats = 32 lanes x 16 B
+      dma16(uniform_pointer((wave == 0 && !kFold ? p.s : p.t) + j0), (me & 31u) * 16u,
             lds0 + kBuffers * kRowBytes + (uint32_t)(k & (kTermSlots - 1)) * kTermBytes
-                + (uint32_t)wave * (kTileB * 4));
+                + (uint32_t)(kFold ? 1 : wave) * (kTileB * 4));
   };
 
   // stage the a-block through LDS once (coalesced), then keep ALL its fragments in registers
@@ -170,11 +189,11 @@ __global__ __launch_bounds__(kThreads, 1) void k_pairwise(const PairArgs p) {
       af[at][ks] = *reinterpret_cast<const f16x8*>(
           smem + kRowBytes + off256(128 * wa + 32 * at + r, 2 * ks + hq));
 
-  float best[4];
+  float best[4];   // running minimum of key (kFold: running maximum of g = -key / 2)
   int bidx[4];
 #pragma unroll
   for (int at = 0; at < 4; ++at) {
-    best[at] = __builtin_inff();
+    best[at] = kFold ? -__builtin_inff() : __builtin_inff();
     bidx[at] = 0x7fffffff;
   }
 
@@ -182,18 +201,31 @@ __global__ __launch_bounds__(kThreads, 1) void k_pairwise(const PairArgs p) {
   __syncthreads();
   const int tiles = j_begin < j_end ? (int)((j_end - j_begin + kTileB - 1) / kTileB) : 0;
   if (tiles > 1) request(1);
-  if (tiles > 2) request(2);
+  if (tiles > 2 && (kDense || GFY_PAIRWISE_TILES_PER_BARRIER != 2)) request(2);
 
   // the wave's 32 x 128 block of tile k: four independent accumulator chains (a 32x32x16
   // MFMA that reads the previous one's result stalls the issue port), the b operand read
   // kAheadK k-steps ahead
   f32x16 acc[4];   // [at]
-  auto multiply = [&](int k) {
+  const int jw = 32 * wb + 4 * hq;   // first of this lane's b-rows inside a tile
+  auto multiply = [&](int k) __attribute__((always_inline)) {
     const char* tile = smem + (k & (kBuffers - 1)) * kRowBytes;
+    f32x16 start;    // what every chain starts from: 0, or (kFold) -|b_j|^2 / 2 of the lane's 16 b-rows
+    if constexpr (kFold) {
+      const float* u_l = reinterpret_cast<const float*>(
+          smem + kBuffers * kRowBytes + (k & (kTermSlots - 1)) * kTermBytes) + kTileB;
 #pragma unroll
-    for (int at = 0; at < 4; ++at)
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 uv = *reinterpret_cast<const f32x4*>(u_l + jw + 8 * g);
 #pragma unroll
-      for (int q = 0; q < 16; ++q) acc[at][q] = 0.f;
+        for (int i = 0; i < 4; ++i) start[4 * g + i] = uv[i];
+      }
+    } else {
+#pragma unroll
+      for (int at = 0; at < 4; ++at)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[at][q] = 0.f;
+    }
     constexpr int kAheadK = 2, kRing = kAheadK + 1;
     f16x8 bf[kRing];   // [ks % kRing]
 #pragma unroll
@@ -209,14 +241,14 @@ __global__ __launch_bounds__(kThreads, 1) void k_pairwise(const PairArgs p) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int at = 0; at < 4; ++at)
-        acc[at] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ks % kRing], af[at][ks], acc[at],
+        acc[at] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ks % kRing], af[at][ks],
+                                                         kFold && ks == 0 ? start : acc[at],
                                                          0, 0, 0);
     }
   };
 
   // what happens to the products of tile k (still in acc)
-  const int jw = 32 * wb + 4 * hq;   // first of this lane's b-rows inside a tile
-  auto reduce = [&](int k) {
+  auto reduce = [&](int k) __attribute__((always_inline)) {
     const int64_t j0 = j_begin + (int64_t)k * kTileB;
     const float* s_l = reinterpret_cast<const float*>(
         smem + kBuffers * kRowBytes + (k & (kTermSlots - 1)) * kTermBytes);
@@ -248,6 +280,34 @@ __global__ __launch_bounds__(kThreads, 1) void k_pairwise(const PairArgs p) {
           }
         }
       }
+    } else if constexpr (kFold) {
+      const int64_t ex_lo = a0 + p.exclude_offset, ex_hi = ex_lo + kBlockA;
+      const bool may_exclude = p.exclude_on && ex_lo < j0 + kTileB && ex_hi > j0;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int at = 0; at < 4; ++at) {
+        if (may_exclude) {   // block-uniform, at most three tiles per block
+          const int64_t off = (a0 + p.exclude_offset - j0) + (128 * wa + 32 * at + r - jw);
+          const int d = off >= 0 && off < 32 ? (int)off : 4;   // 4: not a position of this lane
+          const int slot = (d & 4) ? -1 : (d >> 3) * 4 + (d & 3);
+#pragma unroll
+          for (int q = 0; q < 16; ++q) acc[at][q] = q == slot ? -__builtin_inff() : acc[at][q];
+        }
+        float high = __builtin_fmaxf(acc[at][0], acc[at][1]);
+#pragma unroll
+        for (int q = 2; q < 16; q += 2)
+          high = __builtin_fmaxf(__builtin_fmaxf(high, acc[at][q]), acc[at][q + 1]);   // v_max3_f32
+        const bool better = high > best[at];   // strict: an earlier tile keeps a tie
+        if (__ballot(better)) {                // wave-uniform skip once the sweep has settled
+          int first = 15;                      // lowest position holding the maximum
+#pragma unroll
+          for (int q = 14; q >= 0; --q) first = acc[at][q] == high ? q : first;
+          const int j = (int)(j0 + jw + 8 * (first >> 2) + (first & 3));
+          best[at] = better ? high : best[at];
+          bidx[at] = better ? j : bidx[at];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     } else {
       // does this tile contain an excluded (i, i + offset) pair of this block?
       const int64_t ex_lo = a0 + p.exclude_offset, ex_hi = ex_lo + kBlockA;
@@ -304,12 +364,13 @@ __global__ __launch_bounds__(kThreads, 1) void k_pairwise(const PairArgs p) {
   // to two) younger requests stay in flight, 4 per request, 5 on the waves that fetch
   // (s, t) — then the barrier, which publishes everybody's share and says that the rows of
   // tile k - 1 are no longer being read, so tile k + 3 can be requested into their buffer.
-  auto sync = [&](int k) {
+  auto sync = [&](int k) __attribute__((always_inline)) {
     const int younger = tiles - 1 - k < 2 ? tiles - 1 - k : 2;
+    const bool fetches_terms = wave < (kFold ? 1 : 2);
     if (younger == 2) {
-      if (wave < 2) __builtin_amdgcn_s_waitcnt(0x0F7A); else __builtin_amdgcn_s_waitcnt(0x0F78);
+      if (fetches_terms) __builtin_amdgcn_s_waitcnt(0x0F7A); else __builtin_amdgcn_s_waitcnt(0x0F78);
     } else if (younger == 1) {
-      if (wave < 2) __builtin_amdgcn_s_waitcnt(0x0F75); else __builtin_amdgcn_s_waitcnt(0x0F74);
+      if (fetches_terms) __builtin_amdgcn_s_waitcnt(0x0F75); else __builtin_amdgcn_s_waitcnt(0x0F74);
     } else {
       __builtin_amdgcn_s_waitcnt(0x0F70);
     }
@@ -320,14 +381,57 @@ __global__ __launch_bounds__(kThreads, 1) void k_pairwise(const PairArgs p) {
 
   // (Running the two waves of a SIMD half a tile out of phase — one multiplies while the other
   // reduces — was measured: no change, see profiles/README.md.)
-  for (int ti = 0; ti < tiles; ++ti) {
-    sync(ti);
-    multiply(ti);
-    reduce(ti);
+  if constexpr (GFY_PAIRWISE_TILES_PER_BARRIER == 2 && !kDense) {
+    // Two tiles per barrier: the ring holds the pair being consumed and the pair in flight.
+    // Between two barriers each wave runs multiply, reduce, multiply, reduce on its own, so
+    // the two waves of a SIMD interleave (one reduces under the other's MFMAs) and the matrix
+    // core only idles for one reduce per PAIR of tiles.
+    // (-DGFY_PW_NO_*: timing experiments, results are garbage — profiles/README.md)
+    auto reduce_x = [&](int k) __attribute__((always_inline)) {
+#ifdef GFY_PW_NO_REDUCE
+#pragma unroll
+      for (int at = 0; at < 4; ++at) best[at] = __builtin_fmaxf(best[at], acc[at][0]);
+#else
+      reduce(k);
+#endif
+    };
+    // kFold: waves 4..7 (the second wave of every SIMD) carry the reduce of a pair's second
+    // tile over the barrier — it reads registers only — so that the two waves of a SIMD leave
+    // the barrier one reduce apart and stay that way: one reduces while the other multiplies.
+    // (Not for the (s, t) form: its reduce reads the term ring, whose slot the requests after
+    // the barrier refill.)
+    const bool late = kFold && wave >= 4;
+    int carried = -1;
+    for (int ti = 0; ti < tiles; ti += 2) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): this wave's share of the pair
+      asm volatile("" ::: "memory");
+      __syncthreads();                             // everybody's share; the previous pair is spent
+      if (ti + 2 < tiles) request(ti + 2);
+      if (ti + 3 < tiles) request(ti + 3);
+      if (carried >= 0) reduce_x(carried);
+      carried = -1;
+      multiply(ti);
+      reduce_x(ti);
+      if (ti + 1 < tiles) {
+        multiply(ti + 1);
+        if (late) carried = ti + 1; else reduce_x(ti + 1);
+      }
+    }
+    if (carried >= 0) reduce_x(carried);
+  } else {
+    for (int ti = 0; ti < tiles; ++ti) {
+      sync(ti);
+      multiply(ti);
+      reduce(ti);
+    }
   }
   __syncthreads();   // the result merge below reuses the first buffer
 
   if constexpr (!kDense) {
+    if constexpr (kFold) {   // back to keys: -2 g is exact, order and ties carry over
+#pragma unroll
+      for (int at = 0; at < 4; ++at) best[at] *= -2.0f;
+    }
     // merge the two lane halves (different b-rows, same a-row), then the two
     // waves that share this a-row range (wb = 0/1) through LDS
     float* m_val = reinterpret_cast<float*>(smem);          // [4 wb][kBlockA]
@@ -441,6 +545,8 @@ static int opt_in_pairwise_lds() {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kPairLds));
     GFY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise<true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kPairLds));
+    GFY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise<false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kPairLds));
     return GFY_OK;
   });
 }
@@ -455,8 +561,9 @@ int launch_pairwise_nearest(const void* a, int64_t n, const void* b, int64_t m,
   const f16* ap = (const f16*)a;
   const f16* bp = (const f16*)b;
   const int64_t padded_m = (m + kTileB - 1) / kTileB * kTileB;
-  k_row_terms<<<(int)((padded_m * 16 + 255) / 256), 256, 0, s>>>(bp, m, padded_m, metric, w.s, w.t, nullptr);
-  k_row_terms<<<(int)((n * 16 + 255) / 256), 256, 0, s>>>(ap, n, n, metric, nullptr, nullptr, w.a_term);
+  const int fold = metric == GFY_L2;
+  k_row_terms<<<(int)((padded_m * 16 + 255) / 256), 256, 0, s>>>(bp, m, padded_m, metric, fold, w.s, w.t, nullptr);
+  k_row_terms<<<(int)((n * 16 + 255) / 256), 256, 0, s>>>(ap, n, n, metric, 0, nullptr, nullptr, w.a_term);
   PairArgs p{};
   p.a = ap;
   p.b = bp;
@@ -474,7 +581,8 @@ int launch_pairwise_nearest(const void* a, int64_t n, const void* b, int64_t m,
   p.part_val = w.part_val;
   p.part_idx = w.part_idx;
   if (const int rc = opt_in_pairwise_lds()) return rc;
-  k_pairwise<false><<<w.blocks_a * w.chunks, kThreads, kPairLds, s>>>(p);
+  if (fold) k_pairwise<false, true><<<w.blocks_a * w.chunks, kThreads, kPairLds, s>>>(p);
+  else k_pairwise<false><<<w.blocks_a * w.chunks, kThreads, kPairLds, s>>>(p);
   k_nearest_finish<<<(int)((n + 255) / 256), 256, 0, s>>>(
       w.part_val, w.part_idx, w.a_term, n, w.chunks, metric, best_val, best_idx);
   GFY_CHECK_HIP(hipGetLastError());
@@ -493,8 +601,8 @@ int launch_pairwise_dense(const void* a, int64_t n, const void* b, int64_t m,
   const f16* ap = (const f16*)a;
   const f16* bp = (const f16*)b;
   const int64_t padded_m = (m + kTileB - 1) / kTileB * kTileB;
-  k_row_terms<<<(int)((padded_m * 16 + 255) / 256), 256, 0, s>>>(bp, m, padded_m, metric, sv, tv, nullptr);
-  k_row_terms<<<(int)((n * 16 + 255) / 256), 256, 0, s>>>(ap, n, n, metric, nullptr, nullptr, at);
+  k_row_terms<<<(int)((padded_m * 16 + 255) / 256), 256, 0, s>>>(bp, m, padded_m, metric, 0, sv, tv, nullptr);
+  k_row_terms<<<(int)((n * 16 + 255) / 256), 256, 0, s>>>(ap, n, n, metric, 0, nullptr, nullptr, at);
   PairArgs p{};
   p.a = ap;
   p.b = bp;
