@@ -10,23 +10,31 @@ with the ranks' status.  Under torch.distributed.run it is one rank.
 
 One step = one pass of the hot path over one shard: COO→CSR build, per-encode setup (tile
 plans + input Linear, 1 launch), 4 fused GINE layer launches the last of which also runs
-head + float64 L2 normalise, embeddings left on the device.  Multi-GPU: shards
-are independent, every rank encodes its own shards, there is no data-path collective
-("weak" scaling); the only communication is the barrier and the MAX-reduction of the
-elapsed time.
+head + float64 L2 normalise, embeddings left on the device.  The steps are issued
+``--batch`` shards at a time (default 4) through ``gfy_encode_coo_batch`` — the shards of a
+batch share every launch (one graph of 240,000 nodes in global numbering; the layers run as
+the persistent-rounds kernel k_gine_layer_q), as ``encode_graphs`` issues the micro-batches of
+one shard — with ``--streams`` batches in flight (default 2).  ``--batch 1`` is one shard per
+launch sequence (the one-round kernel k_gine_layer_f16).  K and W count SHARDS either way.
+Multi-GPU: shards are independent, every rank encodes its own shards, there is no data-path
+collective ("weak" scaling); the only communication is the barrier and the MAX-reduction of
+the elapsed time.
 
 Before the W warm-up steps the script runs the same steps untimed for 0.25 s
 (GFY_BENCH_SETTLE_S): set-up, so that every pre-bound step exists and the part has
 reached its working clocks whatever K and W are.  Then W warm-up steps, barrier +
-synchronize, EXACTLY K timed steps, synchronize, MAX over ranks.
+synchronize, EXACTLY K timed steps, synchronize, MAX over ranks.  When those K steps took less
+than 10 ms (the driver's K=20 is 1.5 ms) the same leg is repeated until 10 ms are covered and
+reported beside the contract values (``timed_ms``, ``repeated``); ``value`` stays the K-step one.
 
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
-  roofline      dominant kernel (k_gine_layer_f16): algorithmic bytes per launch
-                (512·N + 9·E + layer weights) ÷ its mean duration IN THE
+  roofline      dominant kernel (k_gine_layer_q, or k_gine_layer_f16 with --batch 1):
+                algorithmic bytes per launch ((512·N + 9·E) x the shards of one launch + layer
+                weights) ÷ its mean duration IN THE
                 TIMED CONFIGURATION (all streams in flight), taken on the device clock by
                 the launches themselves (first workgroup start -> last workgroup end,
                 gfy_encoder_set_timing(3): an event pair on one stream would include the
-                other streams' kernels); `isolated` repeats it one shard at a time with
+                other streams' kernels); `isolated` repeats it one batch at a time with
                 HIP events around the launches; `traffic`
                 = HBM bytes per launch from the committed PMC passes, only while they
                 were taken from the kernel source as it is now (else null)
