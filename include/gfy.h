@@ -136,7 +136,13 @@ int gfy_build_csr(const int32_t* edge_index, const uint8_t* edge_types,
  *   out           [n_out_rows][out_dim] of out_dtype (f16 / f32 / f64)
  *   normalise     1: out = o / max(||o||_2, 1e-12) computed in float64 and
  *                 rounded once to out_dtype (api.py:250-252,258-259);
- *                 0: raw head output o                                          */
+ *                 0: raw head output o
+ * Output dtypes of the fp16 model are separate code paths: out_dtype f16 runs head + normalise
+ * inside the last layer launch, f32 / f64 run the stand-alone head kernel, and the two sum the
+ * head's 128-deep dot products in different k orders (fp32 accumulation either way).  Each is
+ * deterministic and within 1e-3 of the reference, but an f32 result rounded to fp16 is NOT
+ * guaranteed to be the f16 call's bytes: fewer than 2e-3 of the elements differ, by at most
+ * 2.5e-4 (tests/test_gpu_parity.py::test_fused_head_equals_standalone_head).                */
 size_t gfy_encode_workspace_bytes(const gfy_encoder* encoder, int64_t n_nodes,
                                   int64_t n_edges);
 int gfy_encode(gfy_encoder* encoder, const float* node_features,
