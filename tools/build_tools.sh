@@ -9,6 +9,6 @@ hipcc -O2 tools/gfy_bench.cpp -Iinclude -Lginfinity_amd/csrc -lgfy "$RP" -o tool
 if [ -f ginfinity_amd/csrc/libgfy_stamps.so ]; then
   hipcc -O2 -DGFY_STAMPS tools/gfy_bench.cpp -Iinclude -Lginfinity_amd/csrc -lgfy_stamps "$RP" -o tools/gfy_bench_stamps
 fi
-for p in clockcheck probe dma_probe dma_rate coherence_probe mfma_peak isa_semantics valu_rate; do
+for p in clockcheck probe dma_probe dma_rate coherence_probe mfma_peak isa_semantics valu_rate overlap_probe; do
   hipcc -O3 --offload-arch=gfx950 tools/$p.hip -o tools/$p
 done
