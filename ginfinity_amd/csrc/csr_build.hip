@@ -29,7 +29,7 @@ constexpr int kScanItems = 8;  // per thread
 constexpr int kScanTile = kScanBlock * kScanItems;
 constexpr int kDirectScanTiles = 64;   // up to here every scan block sums its own prefix
 
-constexpr int kCountEdgesPerBlock = 256;   // one per thread (1,024: 8.9 us, 256: 7.5 us at E = 300,000)
+constexpr int kCountEdgesPerBlock = kCsrCountEdgesPerBlock;   // gfy_common.h
 
 // kTileSums: also leave the number of edges per 32 destination rows (what the scan-free finish
 // sums).  One global atomic per edge would double the kernel (300 k more atomics: 6.5 -> 12 us,

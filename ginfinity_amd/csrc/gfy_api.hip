@@ -716,7 +716,7 @@ static int batch_table(const gfy_shard* shards, int count, const char* who, Shar
     t.out[s] = one.out;
     tiles += (one.n_nodes + 31) / 32;
     edges += one.n_edges;
-    blocks += (one.n_edges + 255) / 256;
+    blocks += (one.n_edges + kCsrCountEdgesPerBlock - 1) / kCsrCountEdgesPerBlock;
     GFY_REQUIRE(tiles * 32 <= ((int64_t)1 << 24) && edges < INT32_MAX, GFY_ERR_UNSUPPORTED,
                 "%s: a batch holds at most 16,777,216 (padded) nodes and 2^31 - 1 edges", who);
   }

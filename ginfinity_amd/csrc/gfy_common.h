@@ -217,6 +217,12 @@ struct ShardTable {
 // COO -> CSR scratch (csr_build.hip, csr_finish.inc), all in the caller's workspace
 constexpr int kCsrSlots = 8;        // edge ids kept per row in the table (= plan slots)
 constexpr int kCsrTileRows = 32;    // rows finished by one 256-thread block (= layer tile)
+#ifndef GFY_COUNT_EDGES_PER_BLOCK
+#define GFY_COUNT_EDGES_PER_BLOCK 256
+#endif
+// edges per block of k_csr_count, 256 = one per thread (E = 300,000: 1,024 per block 8.9 us,
+// 256 per block 7.5 us); ShardTable::count_block_base is in these units
+constexpr int kCsrCountEdgesPerBlock = GFY_COUNT_EDGES_PER_BLOCK;
 constexpr int kCsrLocalScanTiles = 4096;   // up to here the finish stage derives row_ptr itself
 constexpr int kCsrStageFarRows = 40;   // out-of-tile rows a gather stage holds (= kLFar, gine_layer.inc)
 constexpr uint32_t kCsrNoSource = 0xFFFFFFu;   // table entry: the edge's source is outside its shard
