@@ -110,6 +110,24 @@ def _advise_huge_pages(block: np.ndarray) -> None:
         pass
 
 
+class _ParameterView:
+    """``parameters()`` / ``state_dict()`` of the loaded checkpoint as torch tensors."""
+
+    def __init__(self, state: dict, dtype: torch.dtype) -> None:
+        self._state, self._dtype = state, dtype
+
+    def state_dict(self) -> dict:
+        return {name: (torch.from_numpy(np.array(value)).to(self._dtype)
+                       if np.issubdtype(value.dtype, np.floating)
+                       else torch.from_numpy(np.array(value)))
+                for name, value in self._state.items()}
+
+    def parameters(self):
+        for name, value in self.state_dict().items():
+            if "running_" not in name and "num_batches_tracked" not in name:
+                yield value
+
+
 class _Downloader:
     """Device block → the caller's (pageable) host memory through a ring of pinned staging
     buffers: the DMA runs at PCIe speed into pinned memory and the copy out of it is a plain
@@ -289,6 +307,7 @@ class Ginfinity:
         self._preparer: ThreadPoolExecutor | None = None
         self._uploader: _Uploader | None = None
         self._metadata = checkpoint.metadata
+        self._state = checkpoint.state
         self._config = checkpoint.config
         self._graph_spec = checkpoint.graph_spec
         self.device = device
@@ -329,6 +348,13 @@ class Ginfinity:
         return loaded
 
     # -- metadata -----------------------------------------------------------------
+    @property
+    def _model(self) -> "_ParameterView":
+        """What remains of the reference's ``torch.nn`` module here: its parameters, in the
+        dtype the encoder computes with (api.py:110-113: ``model.half()`` unless
+        ``full_precision``) — read-only copies; the compute uses the weight pack in libgfy."""
+        return _ParameterView(self._state, torch.float32 if self.full_precision else torch.float16)
+
     @property
     def embedding_dimension(self) -> int:
         return self._config.out_dim

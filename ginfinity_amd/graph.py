@@ -754,8 +754,8 @@ def partition_records(records: Iterable[RNA], *, max_records: int,
         yield tuple(group)
 
 
-from .shard_io import (graph_metadata_path, load_graph_shard,  # noqa: E402
-                       save_graph_shard)
+from .shard_io import (_file_sha256 as _sha256,  # noqa: E402,F401  (what shard I/O hashes with)
+                       graph_metadata_path, load_graph_shard, save_graph_shard)
 
 __all__ = [
     "GRAPH_SHARD_FORMAT", "GRAPH_SHARD_FORMAT_VERSION", "NODE_ROLE_CONTEXT",

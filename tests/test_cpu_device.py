@@ -137,3 +137,29 @@ def test_cli_embed_graphs_on_cpu_from_the_reference_s_shard(tmp_path):
     assert set(mine) == set(reference)
     assert mine["records"] == reference["records"]
     assert mine["graph_spec_sha256"] == reference["graph_spec_sha256"]
+
+
+def test_loaded_parameters_have_the_compute_dtype_and_hashing_stays_opt_in(tmp_path, monkeypatch):
+    """Two things the reference's own tests reach for below the public surface
+    (tests/test_api.py:24,29: ``next(encoder._model.parameters()).dtype``;
+    tests/test_graph.py:75-86: ``graph._sha256`` replaced to prove that loading a shard with
+    the default options does not hash its tensors).  `tools/run_reference_tests.sh` runs those
+    test files themselves against this package where the reference tree exists."""
+    import torch
+    from ginfinity_amd import (Ginfinity, GraphBuilder, RNA, graph, load_graph_shard,
+                               save_graph_shard)
+    half, full = Ginfinity.load(), Ginfinity.load(full_precision=True)
+    assert next(half._model.parameters()).dtype == torch.float16
+    assert next(full._model.parameters()).dtype == torch.float32
+    assert sum(p.numel() for p in half._model.parameters()) == half.info()["parameter_count"]
+    shard = GraphBuilder().build_shard([RNA("a", "ACGUACGU", "((....))")])
+    tensor_path, _ = save_graph_shard(shard, tmp_path / "one.safetensors", checksum=True)
+
+    def unexpected(_path):
+        raise AssertionError("content hashing must remain opt-in")
+
+    monkeypatch.setattr(graph, "_sha256", unexpected)
+    loaded = load_graph_shard(tensor_path)                  # default: no hashing
+    assert loaded.identifiers == ("a",)
+    with pytest.raises(AssertionError, match="opt-in"):
+        load_graph_shard(tensor_path, verify_checksum=True)
