@@ -560,6 +560,7 @@ def main() -> None:
             "kernels_ms": kernels,
         }))
     if distributed:
+        fence()          # rank 0's extra measurements are over: the ranks leave together
         dist.destroy_process_group()
 
 
