@@ -336,11 +336,23 @@ def main() -> None:
     distributed = "RANK" in os.environ
     if distributed and world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    # Rehearsal switches (no multi-GPU box was ever available to this build): the ranks' control
+    # flow — fences, MAX-reductions, the repeated leg, who prints — can be run with all ranks on
+    # ONE GPU over gloo: GFY_BENCH_BACKEND=gloo GFY_BENCH_ONE_DEVICE=1.  The line then says so
+    # (config.rehearsal) and its value is not a scaling figure.
+    backend = os.environ.get("GFY_BENCH_BACKEND", "nccl")
+    one_device = os.environ.get("GFY_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     if distributed:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     device = torch.device("cuda", local_rank)
+    reduce_device = device if backend == "nccl" else torch.device("cpu")
     torch.cuda.set_device(device)
     if args.workload == "cross-shard":
         cross_shard(args, rank, local_rank, world, distributed)
@@ -413,7 +425,7 @@ def main() -> None:
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - began
     if distributed:
-        worst = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        worst = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(worst, op=dist.ReduceOp.MAX)
         elapsed = float(worst.item())
     fence()
@@ -431,7 +443,7 @@ def main() -> None:
         torch.cuda.synchronize(device)
         long_elapsed = time.perf_counter() - began
         if distributed:
-            worst = torch.tensor([long_elapsed], dtype=torch.float64, device=device)
+            worst = torch.tensor([long_elapsed], dtype=torch.float64, device=reduce_device)
             dist.all_reduce(worst, op=dist.ReduceOp.MAX)
             long_elapsed = float(worst.item())
         fence()
@@ -554,7 +566,10 @@ def main() -> None:
                        "nodes_per_step": NODES, "edges_per_step": EDGES,
                        "shards_per_rank": POOL, "streams_per_gpu": lanes,
                        "shards_per_launch": batch,
-                       "rccl_ranks": dist.get_world_size() if distributed else 0,
+                       "rccl_ranks": dist.get_world_size() if distributed and backend == "nccl" else 0,
+                       **({"rehearsal": f"{world} ranks over {backend}"
+                                        + (" sharing ONE GPU" if one_device else "")}
+                          if backend != "nccl" or one_device else {}),
                        "parallelism": f"shard-parallel x{world}"},
             "roofline": roofline, "cpu_baseline": baseline, "distance": distance,
             "kernels_ms": kernels,

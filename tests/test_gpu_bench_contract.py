@@ -74,3 +74,27 @@ def test_cross_shard_workload_through_the_launcher():
     assert line["n_gpus"] == 1 and line["config"]["rccl_ranks"] == 1
     assert line["config"]["rows_total"] == 120_000 and line["unit"] == "pairs/s"
     assert line["encode"]["nodes_per_s"] > 1e6 and line["exchange_and_search"]["tflops"] > 1.0
+
+
+def test_two_ranks_rehearsed_on_one_gpu_over_gloo():
+    """No multi-GPU box was available to this build: the control flow of N > 1 — two rank
+    processes under torch.distributed.run, barrier fences, MAX-reduction of the elapsed time,
+    the repeated leg with the same count on both ranks, rank 0 alone printing, the ranks
+    leaving together — is run with both ranks on this box's ONE GPU over gloo
+    (GFY_BENCH_BACKEND / GFY_BENCH_ONE_DEVICE in bench.py).  `value` counts both ranks' shards."""
+    env = dict(os.environ, GFY_BENCH_SETTLE_S="0.05", GFY_BENCH_BACKEND="gloo",
+               GFY_BENCH_ONE_DEVICE="1")
+    done = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+         "--master-addr", "127.0.0.1", "--master-port", "29531", str(ROOT / "bench.py"),
+         "--gpus", "2", "--steps", "40", "--warmup", "8"],
+        cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0, done.stderr[-2000:]
+    lines = [line for line in done.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1, done.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"] == 0
+    assert "sharing ONE GPU" in line["config"]["rehearsal"]
+    assert line["cpu_baseline"] is None and line["distance"] is None      # N = 1 only
+    assert abs(line["value"] - 2 * 60000 / (line["ms_per_step"] * 1e-3)) < 1e-3 * line["value"]
+    assert line["repeated"]["repeats"] >= 1 and line["value"] > 1e8
