@@ -16,11 +16,13 @@ module.  Differences a user can observe, all deliberate:
 * the per-record arrays returned by one call are views into one host block
   (C-contiguous, independent rows) instead of separate allocations, unless
   ``encoder.independent_outputs = True``;
-* ``load(..., pinned_outputs=True)`` (not in the reference; off by default): that one host
-  block is page-locked memory from torch's caching host allocator and the embeddings are
-  DMA'd straight into it — no staging copy on the host, the call runs at PCIe speed.  The
-  arrays are ordinary numpy views; the block returns to the allocator's cache when the last
-  of them is dropped.
+* on the GPU that host block is page-locked memory from torch's caching host allocator and the
+  embeddings are DMA'd straight into it — no staging copy on the host, the call runs at PCIe
+  speed (``load(..., pinned_outputs=...)``, not in the reference: ``None`` = this default,
+  ``False`` = pageable memory through a staging ring, ``True`` = always).  The arrays are
+  ordinary numpy views; the block returns to the allocator's cache when the last of them is
+  dropped, and while results worth more than ``PINNED_RESULT_LIMIT`` bytes are alive the default
+  falls back to pageable memory (page-locked memory cannot be swapped).
 """
 from __future__ import annotations
 
@@ -108,6 +110,26 @@ def _advise_huge_pages(block: np.ndarray) -> None:
             libc.madvise(ctypes.c_void_p(first), ctypes.c_size_t(last - first), 14)  # MADV_HUGEPAGE
     except Exception:       # pragma: no cover - advisory only
         pass
+
+
+#: default mode only: results alive beyond this many page-locked bytes go to pageable memory
+PINNED_RESULT_LIMIT = 4 << 30
+_pinned_alive = [0]                     # bytes of page-locked result blocks not yet dropped
+
+
+def _pinned_block(shape, dtype: torch.dtype) -> torch.Tensor:
+    """A page-locked host tensor whose bytes count against PINNED_RESULT_LIMIT while it lives
+    (the numpy views handed to the caller keep it alive)."""
+    import weakref
+    block = torch.empty(shape, dtype=dtype, pin_memory=True)
+    size = block.numel() * block.element_size()
+    _pinned_alive[0] += size
+    weakref.finalize(block, _pinned_released, size)
+    return block
+
+
+def _pinned_released(size: int) -> None:
+    _pinned_alive[0] -= size
 
 
 class _ParameterView:
@@ -206,7 +228,8 @@ class _DirectDownloader:
             destination.copy_(block, non_blocking=True)
             done = torch.cuda.Event()
             done.record(stream)
-        block.record_stream(stream)                   # its memory is reused only after the DMA
+        # (no record_stream: `block` is a row range of the encoder's own device block, which is
+        # next written by a later call — after this call's copies have landed)
         return self._Landed(done)
 
 
@@ -304,6 +327,7 @@ class Ginfinity:
         self._host = host
         self._copier: _Downloader | None = None
         self._direct: _DirectDownloader | None = None
+        self._device_block: torch.Tensor | None = None
         self._preparer: ThreadPoolExecutor | None = None
         self._uploader: _Uploader | None = None
         self._metadata = checkpoint.metadata
@@ -317,16 +341,18 @@ class Ginfinity:
         #: micro-batch are row ranges of ONE host block (no per-record copy — keeping a single
         #: record alive keeps its block alive)
         self.independent_outputs = False
-        #: True: the host block of a call is page-locked memory (torch's caching host
-        #: allocator) and the device writes into it directly; see the module docstring
-        self.pinned_outputs = False
+        #: None (default): the host block of a call is page-locked memory (torch's caching
+        #: host allocator) and the device writes into it directly, unless more than
+        #: PINNED_RESULT_LIMIT bytes of earlier results are still alive; True: always;
+        #: False: pageable memory through the staging ring.  See the module docstring.
+        self.pinned_outputs: bool | None = None
 
     @classmethod
     def load(cls, device: str = "cpu", *,
              allow_nondeterministic_cuda: bool = False,
              model_dir: str | Path | None = None,
              full_precision: bool = False,
-             pinned_outputs: bool = False) -> "Ginfinity":
+             pinned_outputs: bool | None = None) -> "Ginfinity":
         """Same signature, defaults and device policy as the reference
         (src/ginfinity/api.py:64-76); ``pinned_outputs`` is this build's (module docstring)."""
         if not isinstance(device, str) or (device != "cpu" and not device.startswith("cuda")):
@@ -344,7 +370,7 @@ class Ginfinity:
                                full_precision=full_precision,
                                device=torch.device(device))
         loaded = cls(engine, checkpoint, device, full_precision=full_precision)
-        loaded.pinned_outputs = bool(pinned_outputs)
+        loaded.pinned_outputs = None if pinned_outputs is None else bool(pinned_outputs)
         return loaded
 
     # -- metadata -----------------------------------------------------------------
@@ -421,8 +447,9 @@ class Ginfinity:
         pending, verdicts = [], []
         bounds = microbatch_bounds(lengths, edge_counts, max_batch_nodes, max_batch_edges)
         produced = np.dtype(embedding_dtype) if exact else np.dtype(np.float64)
-        host_block, fetch = self._landing(int(text.node_ptr[-1] - text.node_ptr[0]), produced,
-                                          torch_dtype, exact)
+        total_rows = int(text.node_ptr[-1] - text.node_ptr[0])
+        host_block, fetch = self._landing(total_rows, produced, torch_dtype, exact)
+        device_rows = self._device_rows(total_rows, torch_dtype)
         # the positional columns (numpy sin / cos, GIL released) of later micro-batches are
         # computed on a second helper thread while this one uploads and launches
         if self._preparer is None:
@@ -440,12 +467,12 @@ class Ginfinity:
                 bases, marks, node_ptr, edge_ptr, positional, n1 - n0, e1 - e0,
                 struct_states=1 if spec.struct_feature == "A" else 3,
                 skip2=spec.has_skip2)
+            row = n0 - int(text.node_ptr[0])
             block = engine.encode_coo(features, edge_index, edge_types, out_dtype=torch_dtype,
-                                      normalise=True)
+                                      normalise=True, out=device_rows[row:row + n1 - n0])
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(device))
             verdicts.append((start, first_invalid))
-            row = n0 - int(text.node_ptr[0])
             pending.append((fetch(block, ready, row, n1 - n0),
                             row, n1 - n0, lengths[start:stop]))
         outputs: list[np.ndarray] = []
@@ -522,7 +549,9 @@ class Ginfinity:
         uploader = self._uploader
         core_counts = shard.core_count_array()
         produced = np.dtype(embedding_dtype) if exact else np.dtype(np.float64)
-        host_block, fetch = self._landing(int(core_counts.sum()), produced, torch_dtype, exact)
+        total_rows = int(core_counts.sum())
+        host_block, fetch = self._landing(total_rows, produced, torch_dtype, exact)
+        device_rows = self._device_rows(total_rows, torch_dtype)
 
         def prepare(slot: int, start: int, stop: int):
             # the arrays of GraphShard.slice(start, stop) (graph.py:414-444: edge indices
@@ -557,9 +586,10 @@ class Ginfinity:
             features, edge_index, edge_types, out_rows = uploader.send(packed)
             block = self._engine.encode_coo(features, edge_index, edge_types,
                                             out_rows=out_rows, n_out=kept,
-                                            out_dtype=torch_dtype, normalise=True)
+                                            out_dtype=torch_dtype, normalise=True,
+                                            out=device_rows[first_row:first_row + kept])
             ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream(block.device))
+            ready.record(torch.cuda.current_stream(self._engine.device))
             # (the workers run no interpreter-level loops: a worker cutting 400 views holds the
             # GIL for 0.3 ms at a time and this thread, which needs it between every two
             # enqueues, took 0.6 ms per micro-batch instead of 0.1)
@@ -574,16 +604,35 @@ class Ginfinity:
                 host_block[row:row + kept]))
         return outputs
 
+    def _device_rows(self, rows: int, torch_dtype: torch.dtype) -> torch.Tensor:
+        """[rows, 128] of ``torch_dtype`` on the device, a view of ONE block the encoder keeps
+        (grown when a call needs more): the micro-batches of a call write their embeddings into
+        row ranges of it.  Per-micro-batch output tensors came from torch's caching allocator
+        with ``record_stream`` on the copy stream, so their reuse waited for events and a call
+        could run into ``hipMalloc`` — device-wide, and 15 MB D2H copies next to it took 1.2 ms
+        instead of 0.3 (tools/api_probe3.py).  Safe to reuse call after call: a call returns
+        only when its last copy has landed (one encoder = serialized inference)."""
+        width = self.embedding_dimension
+        need = rows * width * torch.empty((), dtype=torch_dtype).element_size()
+        if self._device_block is None or self._device_block.numel() < need:
+            self._device_block = None                      # release before growing
+            self._device_block = torch.empty(max(need, 1 << 20), dtype=torch.uint8,
+                                             device=self._engine.device)
+        return self._device_block[:need].view(torch_dtype).view(rows, width)
+
     def _landing(self, rows: int, produced: np.dtype, torch_dtype: torch.dtype, exact: bool):
         """The host block of one call and the function that brings a micro-batch's device
         block into rows [first, first + count) of it: ``(host_block, fetch)``;
         ``fetch(block, ready, first, count)`` returns an object whose ``result()`` waits for
         the rows."""
         width = self.embedding_dimension
-        if self.pinned_outputs and exact and not self.independent_outputs:
+        pinned = self.pinned_outputs
+        if pinned is None:
+            pinned = _pinned_alive[0] + rows * width * produced.itemsize <= PINNED_RESULT_LIMIT
+        if pinned and exact and not self.independent_outputs:
             if self._direct is None:
                 self._direct = _DirectDownloader(self._engine.device)
-            landing = torch.empty((rows, width), dtype=torch_dtype, pin_memory=True)
+            landing = _pinned_block((rows, width), torch_dtype)
             direct = self._direct
             return landing.numpy(), lambda block, ready, first, count: direct.submit(
                 block, ready, landing[first:first + count])

@@ -373,35 +373,53 @@ def test_independent_outputs_own_their_memory(gpu_encoder, rouskin_shard):
         gpu_encoder.independent_outputs = False
 
 
-def test_pinned_outputs_give_the_same_arrays(gpu_encoder, rouskin_shard, rouskin_records):
-    """``pinned_outputs``: the call's host block is page-locked and written by the device
-    directly (api._DirectDownloader) — same bytes, same shapes and dtypes, in
-    ``encode_graphs`` and ``encode_many``, for every output dtype; the arrays stay valid
-    after later calls have recycled the allocator's blocks."""
+def test_pinned_and_pageable_results_are_the_same_arrays(gpu_encoder, rouskin_shard,
+                                                         rouskin_records, monkeypatch):
+    """The call's host block is page-locked and written by the device directly
+    (api._DirectDownloader: the default) or pageable and filled through the staging ring
+    (``pinned_outputs=False``) — same bytes, shapes and dtypes, in ``encode_graphs`` and
+    ``encode_many``, for every output dtype; the arrays stay valid after later calls have
+    recycled the allocator's blocks; beyond ``PINNED_RESULT_LIMIT`` bytes of live results the
+    default goes to pageable memory."""
     import gc
+    from ginfinity_amd import api
     shard = rouskin_shard.slice(0, 600)
-    want = {dtype: gpu_encoder.encode_graphs(shard, max_batch_nodes=20_000, embedding_dtype=dtype)
-            for dtype in (np.float16, np.float32, np.float64)}
-    many = gpu_encoder.encode_many(rouskin_records[:300], max_batch_nodes=20_000)
-    gpu_encoder.pinned_outputs = True
+    assert gpu_encoder.pinned_outputs is None
+    gpu_encoder.pinned_outputs = False
     try:
-        kept = {}
-        for dtype, expected in want.items():
-            got = gpu_encoder.encode_graphs(shard, max_batch_nodes=20_000, embedding_dtype=dtype)
-            assert len(got) == len(expected)
-            for a, b in zip(got, expected):
-                assert a.dtype == b.dtype and a.shape == b.shape and a.flags.c_contiguous
+        want = {dtype: gpu_encoder.encode_graphs(shard, max_batch_nodes=20_000,
+                                                 embedding_dtype=dtype)
+                for dtype in (np.float16, np.float32, np.float64)}
+        many = gpu_encoder.encode_many(rouskin_records[:300], max_batch_nodes=20_000)
+        assert not torch.from_numpy(want[np.float16][0]).is_pinned()
+        for mode in (True, None):
+            gpu_encoder.pinned_outputs = mode
+            kept = {}
+            for dtype, expected in want.items():
+                got = gpu_encoder.encode_graphs(shard, max_batch_nodes=20_000,
+                                                embedding_dtype=dtype)
+                assert len(got) == len(expected)
+                assert torch.from_numpy(got[0]).is_pinned()
+                for a, b in zip(got, expected):
+                    assert a.dtype == b.dtype and a.shape == b.shape and a.flags.c_contiguous
+                    assert a.tobytes() == b.tobytes()
+                kept[dtype] = (got[7], expected[7].copy())
+                del got
+                gc.collect()                  # the block survives through the one kept view
+            got_many = gpu_encoder.encode_many(rouskin_records[:300], max_batch_nodes=20_000)
+            for a, b in zip(got_many, many):
                 assert a.tobytes() == b.tobytes()
-            kept[dtype] = (got[7], expected[7].copy())
-            del got
-            gc.collect()                      # the block survives through the one kept view
-        got_many = gpu_encoder.encode_many(rouskin_records[:300], max_batch_nodes=20_000)
-        for a, b in zip(got_many, many):
+            for view, expected in kept.values():
+                np.testing.assert_array_equal(view, expected)
+        del kept, got_many
+        gc.collect()
+        monkeypatch.setattr(api, "PINNED_RESULT_LIMIT", api._pinned_alive[0] + 1024)
+        spilled = gpu_encoder.encode_graphs(shard, max_batch_nodes=20_000)
+        assert not torch.from_numpy(spilled[0]).is_pinned()
+        for a, b in zip(spilled, want[np.float16]):
             assert a.tobytes() == b.tobytes()
-        for view, expected in kept.values():
-            np.testing.assert_array_equal(view, expected)
     finally:
-        gpu_encoder.pinned_outputs = False
+        gpu_encoder.pinned_outputs = None
 
 
 # ---- full_precision (fp32 model) ------------------------------------------------------------

@@ -9,7 +9,7 @@ from ginfinity_amd import api
 
 records = read_rna_table(ROOT / "tests" / "golden" / "rouskin_sample_6k.tsv")
 shard = GraphBuilder().build_shard(records)
-enc = Ginfinity.load("cuda", allow_nondeterministic_cuda=True, pinned_outputs=True)
+enc = Ginfinity.load("cuda", allow_nondeterministic_cuda=True)
 enc.encode_graphs(shard)
 enc.encode_graphs(shard)
 
@@ -45,7 +45,8 @@ def enc_coo(*a, **k):
     s = time.perf_counter(); r = orig_enc(*a, **k); trace.append(("encode_coo", s - t0[0], time.perf_counter() - t0[0])); return r
 enc._engine.encode_coo = enc_coo
 out = None
-for rep in range(3):
+import os
+for rep in range(int(os.environ.get("GFY_PROBE_CALLS", "3"))):
     out = None
     trace.clear()
     marks.clear()
@@ -53,13 +54,11 @@ for rep in range(3):
     t0[0] = time.perf_counter()
     out = enc.encode_graphs(shard)
     total = time.perf_counter() - t0[0]
-    print(f"--- call {rep}: {total*1e3:.2f} ms")
     torch.cuda.synchronize()
-    print("gpu-side copy ms:", " ".join(f"{a.elapsed_time(b):.2f}" for a, b, _s, _d in marks))
-    print("gpu-side start of copy i relative to copy 0 start:", " ".join(f"{marks[0][0].elapsed_time(a):.2f}" for a, b, _s, _d in marks))
-    print("source blocks:", " ".join(hex(s_)[-9:] for a, b, s_, _d in marks))
-    for label in ("landing", "pack", "send", "encode_coo", "d2h-enqueue", "landed"):
-        rows = [(a, b) for l, a, b in trace if l == label]
-        if rows:
-            print(f"{label:12s} n={len(rows):3d} sum {sum(b-a for a,b in rows)*1e3:6.2f} ms  first starts {rows[0][0]*1e3:6.2f}  last ends {rows[-1][1]*1e3:6.2f}"
-                  + ("   each end: " + " ".join(f"{b*1e3:.1f}" for a, b in rows) if label in ("landed", "send") else ""))
+    copies = [a.elapsed_time(b) for a, b, _s, _d in marks]
+    last = lambda label: max((b for l, a, b in trace if l == label), default=0.0) * 1e3
+    first = lambda label: min((a for l, a, b in trace if l == label), default=0.0) * 1e3
+    print(f"call {rep:2d}: {total*1e3:6.2f} ms | packs end {last('pack'):5.2f} sends end {last('send'):5.2f} "
+          f"enqueues end {last('d2h-enqueue'):5.2f} first landed {first('landed'):5.2f} last landed {last('landed'):5.2f} | "
+          f"gpu-side copies: sum {sum(copies):5.2f} max {max(copies):5.2f} ms; copy 0 starts -> last ends "
+          f"{marks[0][0].elapsed_time(marks[-1][1]):5.2f} ms", flush=True)
