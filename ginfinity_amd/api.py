@@ -27,6 +27,7 @@ module.  Differences a user can observe, all deliberate:
 from __future__ import annotations
 
 from concurrent.futures import ThreadPoolExecutor
+import collections
 import queue
 
 import json
@@ -203,34 +204,58 @@ class _Downloader:
 
 class _DirectDownloader:
     """Device block → a row range of a PINNED host block, one DMA per micro-batch on one copy
-    stream, issued by the launching thread itself (an enqueue: no worker thread, no host
-    memcpy, nothing to contend for the GIL).  ``pinned_outputs`` only."""
+    stream, no host memcpy, no worker thread.  A copy is ENQUEUED only once the kernels that
+    produce its rows have finished: a copy enqueued behind a still-pending cross-stream
+    dependency was, on most boxes, served at a quarter of the rate (15.4 MB in 1.23 instead of
+    0.31 ms, one to four such copies per call; tools/api_probe3.py).  The launching thread
+    therefore keeps the copies of unfinished micro-batches in a list and enqueues those whose
+    event has happened whenever it passes by (``submit``, ``result``); a helper thread doing
+    the same cost the packers and the launcher 1 ms of a call."""
 
     class _Landed:
-        def __init__(self, event: "torch.cuda.Event") -> None:
-            self._event = event
+        def __init__(self, owner: "_DirectDownloader", block, ready, destination) -> None:
+            self._owner = owner
+            self._job = (block, ready, destination)
+            self._done: "torch.cuda.Event | None" = None
 
         def result(self) -> None:
-            self._event.synchronize()
+            self._owner._pump(until=self)
+            self._done.synchronize()
 
-    def __init__(self, device: torch.device, streams: int = 1) -> None:
-        # (two streams taken in turn share the link: 0.42-0.45 ms per 15 MB copy instead of
-        # 0.31, same total — measured with tools/api_probe3.py)
-        self._streams = [torch.cuda.Stream(device=device) for _ in range(streams)]
-        self._turn = 0
+    def __init__(self, device: torch.device) -> None:
+        self._stream = torch.cuda.Stream(device=device)
+        self._pending: "collections.deque[_DirectDownloader._Landed]" = collections.deque()
+
+    def _pump(self, until: "_DirectDownloader._Landed | None" = None) -> None:
+        """Enqueue, in order, every pending copy whose rows are ready; with ``until``, wait for
+        the events in front of (and of) that copy."""
+        pending = self._pending
+        while pending:
+            head = pending[0]
+            block, ready, destination = head._job
+            if not ready.query():
+                if until is None or until._done is not None:
+                    return
+                ready.synchronize()
+            with torch.cuda.stream(self._stream):
+                destination.copy_(block, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(self._stream)
+            head._done, head._job = done, None
+            pending.popleft()
 
     def submit(self, block: torch.Tensor, ready: "torch.cuda.Event",
                destination: torch.Tensor) -> "_DirectDownloader._Landed":
-        stream = self._streams[self._turn]
-        self._turn = (self._turn + 1) % len(self._streams)
-        stream.wait_event(ready)
-        with torch.cuda.stream(stream):
-            destination.copy_(block, non_blocking=True)
-            done = torch.cuda.Event()
-            done.record(stream)
         # (no record_stream: `block` is a row range of the encoder's own device block, which is
         # next written by a later call — after this call's copies have landed)
-        return self._Landed(done)
+        landed = self._Landed(self, block, ready, destination)
+        self._pending.append(landed)
+        self._pump()
+        return landed
+
+    def abandon(self) -> None:
+        """Forget the copies not yet enqueued (a call that raised)."""
+        self._pending.clear()
 
 
 class _Uploader:
@@ -634,6 +659,7 @@ class Ginfinity:
                 self._direct = _DirectDownloader(self._engine.device)
             landing = _pinned_block((rows, width), torch_dtype)
             direct = self._direct
+            direct.abandon()                  # (copies a call that raised never enqueued)
             return landing.numpy(), lambda block, ready, first, count: direct.submit(
                 block, ready, landing[first:first + count])
         if self._copier is None:

@@ -23,18 +23,8 @@ def wrap(cls, name, label):
 wrap(api._Uploader, "pack", "pack")
 wrap(api._Uploader, "send", "send")
 marks = []
-orig_submit = api._DirectDownloader.submit
-def submit(self, block, ready, destination):
-    a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
-    st = self._streams[self._turn]
-    st.wait_event(ready)
-    a.record(st)
-    r = orig_submit(self, block, ready, destination)
-    b.record(st)
-    marks.append((a, b, block.data_ptr(), destination.data_ptr()))
-    return r
-api._DirectDownloader.submit = submit
 wrap(api._DirectDownloader, "submit", "d2h-enqueue")
+wrap(api._DirectDownloader, "_pump", "pump")
 wrap(api._DirectDownloader._Landed, "result", "landed")
 orig_landing = api.Ginfinity._landing
 def landing(self, *a, **k):
@@ -55,10 +45,9 @@ for rep in range(int(os.environ.get("GFY_PROBE_CALLS", "3"))):
     out = enc.encode_graphs(shard)
     total = time.perf_counter() - t0[0]
     torch.cuda.synchronize()
-    copies = [a.elapsed_time(b) for a, b, _s, _d in marks]
+    copies = [0.0]
     last = lambda label: max((b for l, a, b in trace if l == label), default=0.0) * 1e3
     first = lambda label: min((a for l, a, b in trace if l == label), default=0.0) * 1e3
     print(f"call {rep:2d}: {total*1e3:6.2f} ms | packs end {last('pack'):5.2f} sends end {last('send'):5.2f} "
           f"enqueues end {last('d2h-enqueue'):5.2f} first landed {first('landed'):5.2f} last landed {last('landed'):5.2f} | "
-          f"gpu-side copies: sum {sum(copies):5.2f} max {max(copies):5.2f} ms; copy 0 starts -> last ends "
-          f"{marks[0][0].elapsed_time(marks[-1][1]):5.2f} ms", flush=True)
+          "landed ends: " + " ".join(f"{b*1e3:.1f}" for l, a, b in trace if l == "landed"), flush=True)
