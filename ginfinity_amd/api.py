@@ -189,7 +189,8 @@ class _Downloader:
                 staging = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8,
                                       pin_memory=True)
             stream = torch.cuda.current_stream(self._device)
-            stream.wait_event(ready)
+            ready.synchronize()     # not stream.wait_event: see _DirectDownloader (a copy queued
+            #                         behind a pending cross-stream dependency runs at 1/4 rate)
             view = staging[:nbytes].view(block.dtype).view(block.shape)
             view.copy_(block, non_blocking=True)
             stream.synchronize()
