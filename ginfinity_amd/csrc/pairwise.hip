@@ -33,6 +33,9 @@ constexpr int kBlockA = 256;  // a-rows per workgroup
 constexpr int kTileB = 128;   // b-rows per LDS tile
 constexpr int kThreads = 512;
 constexpr int kBuffers = 4;   // b-tile ring: tile i is consumed while i+1 .. i+3 are in flight
+#ifndef GFY_PAIRWISE_REQUEST_AFTER_MULTIPLY
+#define GFY_PAIRWISE_REQUEST_AFTER_MULTIPLY 1
+#endif
 #ifndef GFY_PAIRWISE_TILES_PER_BARRIER
 #define GFY_PAIRWISE_TILES_PER_BARRIER 2   // nearest: 2 = a barrier per pair of tiles, 1 = per tile
 #endif
@@ -406,11 +409,21 @@ __global__ __launch_bounds__(kThreads, 1) void k_pairwise(const PairArgs p) {
       __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): this wave's share of the pair
       asm volatile("" ::: "memory");
       __syncthreads();                             // everybody's share; the previous pair is spent
+#if GFY_PAIRWISE_REQUEST_AFTER_MULTIPLY == 0
       if (ti + 2 < tiles) request(ti + 2);
       if (ti + 3 < tiles) request(ti + 3);
+#endif
       if (carried >= 0) reduce_x(carried);
       carried = -1;
       multiply(ti);
+#if GFY_PAIRWISE_REQUEST_AFTER_MULTIPLY
+      // the next pair is requested BEHIND the first multiply: issuing a tile's eight DMA
+      // pieces costs a wave several hundred cycles, and right behind the barrier all eight
+      // waves would pay them at once with the matrix cores idle; here waves 0..3 and 4..7 come
+      // by one reduce apart, each under the other's MFMAs
+      if (ti + 2 < tiles) request(ti + 2);
+      if (ti + 3 < tiles) request(ti + 3);
+#endif
       reduce_x(ti);
       if (ti + 1 < tiles) {
         multiply(ti + 1);
