@@ -422,9 +422,14 @@ __global__ __launch_bounds__(kThreads, 1) void k_pairwise(const PairArgs p) {
       // waves would pay them at once with the matrix cores idle; here waves 0..3 and 4..7 come
       // by one reduce apart, each under the other's MFMAs
       if (ti + 2 < tiles) request(ti + 2);
+#if GFY_PAIRWISE_REQUEST_AFTER_MULTIPLY == 1
       if (ti + 3 < tiles) request(ti + 3);
 #endif
+#endif
       reduce_x(ti);
+#if GFY_PAIRWISE_REQUEST_AFTER_MULTIPLY == 2
+      if (ti + 3 < tiles) request(ti + 3);
+#endif
       if (ti + 1 < tiles) {
         multiply(ti + 1);
         if (late) carried = ti + 1; else reduce_x(ti + 1);
