@@ -320,15 +320,25 @@ class _Uploader:
                         raise GraphValidationError("edge index outside shard node range")
         return slot, arrays, offsets, total
 
-    def send(self, packed) -> list[torch.Tensor | None]:
-        """The packed slot → device tensors (views of one allocation), on the current stream."""
+    def send(self, packed, *, mapped: bool = False) -> list[torch.Tensor | None]:
+        """The packed slot → device tensors (views of one allocation), on the current stream.
+        ``mapped``: no copy at all — the tensors returned are the page-locked staging memory
+        itself, which the device reads over PCIe (hipHostMalloc memory is mapped into the
+        device's address space; each input array is read once, by the counting and the set-up
+        kernel).  The caller then says with ``hold`` which event ends those reads.  Used with
+        page-locked results: an H2D copy per micro-batch can land on the copy engine that is
+        busy bringing the embeddings back, and the kernels then wait 0.3 ms per micro-batch for
+        4 MB of input (tools/api_probe5.py: 7.3-7.7 ms per call instead of 6.2-6.6)."""
         slot, arrays, offsets, total = packed
         staging = self._staging[slot]
-        on_device = torch.empty(max(total, 1), dtype=torch.uint8, device=self._device)
-        on_device[:total].copy_(staging[:total], non_blocking=True)
-        done = torch.cuda.Event()
-        done.record(torch.cuda.current_stream(self._device))
-        self._copied[slot] = done
+        if mapped:
+            on_device = staging
+        else:
+            on_device = torch.empty(max(total, 1), dtype=torch.uint8, device=self._device)
+            on_device[:total].copy_(staging[:total], non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(self._device))
+            self._copied[slot] = done
         views: list[torch.Tensor | None] = []
         for array, offset in zip(arrays, offsets):
             if array is None:
@@ -337,6 +347,10 @@ class _Uploader:
             flat = on_device[offset:offset + array.nbytes].view(self._TORCH[array.dtype])
             views.append(flat.view(array.shape))
         return views
+
+    def hold(self, packed, event: "torch.cuda.Event") -> None:
+        """The slot of ``packed`` (sent ``mapped``) is read by the device until ``event``."""
+        self._copied[packed[0]] = event
 
     def __call__(self, arrays: Sequence) -> list[torch.Tensor | None]:
         return self.send(self.pack(self.reserve(), arrays))
@@ -474,7 +488,7 @@ class Ginfinity:
         bounds = microbatch_bounds(lengths, edge_counts, max_batch_nodes, max_batch_edges)
         produced = np.dtype(embedding_dtype) if exact else np.dtype(np.float64)
         total_rows = int(text.node_ptr[-1] - text.node_ptr[0])
-        host_block, fetch = self._landing(total_rows, produced, torch_dtype, exact)
+        host_block, fetch, direct = self._landing(total_rows, produced, torch_dtype, exact)
         device_rows = self._device_rows(total_rows, torch_dtype)
         # the positional columns (numpy sin / cos, GIL released) of later micro-batches are
         # computed on a second helper thread while this one uploads and launches
@@ -576,7 +590,7 @@ class Ginfinity:
         core_counts = shard.core_count_array()
         produced = np.dtype(embedding_dtype) if exact else np.dtype(np.float64)
         total_rows = int(core_counts.sum())
-        host_block, fetch = self._landing(total_rows, produced, torch_dtype, exact)
+        host_block, fetch, direct = self._landing(total_rows, produced, torch_dtype, exact)
         device_rows = self._device_rows(total_rows, torch_dtype)
 
         def prepare(slot: int, start: int, stop: int):
@@ -609,13 +623,15 @@ class Ginfinity:
                 a, b = bounds[len(jobs)]
                 jobs.append(self._preparer.submit(prepare, uploader.reserve(), a, b))
             packed, kept = jobs[index].result()
-            features, edge_index, edge_types, out_rows = uploader.send(packed)
+            features, edge_index, edge_types, out_rows = uploader.send(packed, mapped=direct)
             block = self._engine.encode_coo(features, edge_index, edge_types,
                                             out_rows=out_rows, n_out=kept,
                                             out_dtype=torch_dtype, normalise=True,
                                             out=device_rows[first_row:first_row + kept])
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(self._engine.device))
+            if direct:
+                uploader.hold(packed, ready)
             # (the workers run no interpreter-level loops: a worker cutting 400 views holds the
             # GIL for 0.3 ms at a time and this thread, which needs it between every two
             # enqueues, took 0.6 ms per micro-batch instead of 0.1)
@@ -648,9 +664,9 @@ class Ginfinity:
 
     def _landing(self, rows: int, produced: np.dtype, torch_dtype: torch.dtype, exact: bool):
         """The host block of one call and the function that brings a micro-batch's device
-        block into rows [first, first + count) of it: ``(host_block, fetch)``;
+        block into rows [first, first + count) of it: ``(host_block, fetch, direct)``;
         ``fetch(block, ready, first, count)`` returns an object whose ``result()`` waits for
-        the rows."""
+        the rows; ``direct``: the block is page-locked and written by the device."""
         width = self.embedding_dimension
         pinned = self.pinned_outputs
         if pinned is None:
@@ -662,14 +678,14 @@ class Ginfinity:
             direct = self._direct
             direct.abandon()                  # (copies a call that raised never enqueued)
             return landing.numpy(), lambda block, ready, first, count: direct.submit(
-                block, ready, landing[first:first + count])
+                block, ready, landing[first:first + count]), True
         if self._copier is None:
             self._copier = _Downloader(self._engine.device)
         host_block = np.empty((rows, width), dtype=produced)
         _advise_huge_pages(host_block)
         copier = self._copier
         return host_block, lambda block, ready, first, count: copier.submit(
-            block, ready, lambda host: None, host_block[first:first + count])
+            block, ready, lambda host: None, host_block[first:first + count]), False
 
     def _splitter(self, core_counts, embedding_dtype: np.dtype, exact: bool):
         """host block → the per-record arrays of one micro-batch (views of the block, or
