@@ -500,9 +500,11 @@ class Ginfinity:
             n0, n1 = int(text.node_ptr[start]), int(text.node_ptr[stop])
             e0, e1 = int(text.edge_ptr[start]), int(text.edge_ptr[stop])
             columns = columns_job.result()
-            bases, marks, node_ptr, edge_ptr, positional = self._uploader(
-                (text.bases[n0:n1], text.marks[n0:n1], text.node_ptr[start:stop + 1],
-                 text.edge_ptr[start:stop + 1], columns))
+            packed = self._uploader.pack(self._uploader.reserve(), (
+                text.bases[n0:n1], text.marks[n0:n1], text.node_ptr[start:stop + 1],
+                text.edge_ptr[start:stop + 1], columns))
+            bases, marks, node_ptr, edge_ptr, positional = self._uploader.send(packed,
+                                                                               mapped=direct)
             features, edge_index, edge_types, first_invalid = engine.build_graphs(
                 bases, marks, node_ptr, edge_ptr, positional, n1 - n0, e1 - e0,
                 struct_states=1 if spec.struct_feature == "A" else 3,
@@ -512,6 +514,8 @@ class Ginfinity:
                                       normalise=True, out=device_rows[row:row + n1 - n0])
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(device))
+            if direct:
+                self._uploader.hold(packed, ready)
             verdicts.append((start, first_invalid))
             pending.append((fetch(block, ready, row, n1 - n0),
                             row, n1 - n0, lengths[start:stop]))
