@@ -86,7 +86,7 @@ def test_two_ranks_rehearsed_on_one_gpu_over_gloo():
                GFY_BENCH_ONE_DEVICE="1")
     done = subprocess.run(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-         "--master-addr", "127.0.0.1", "--master-port", "29531", str(ROOT / "bench.py"),
+         "--standalone", "--local-addr", "127.0.0.1", str(ROOT / "bench.py"),   # (a free port)
          "--gpus", "2", "--steps", "40", "--warmup", "8"],
         cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert done.returncode == 0, done.stderr[-2000:]
