@@ -13,7 +13,7 @@ plans + input Linear, 1 launch), 4 fused GINE layer launches the last of which a
 head + float64 L2 normalise, embeddings left on the device.  The steps are issued
 ``--batch`` shards at a time (default 4) through ``gfy_encode_coo_batch`` — the shards of a
 batch share every launch (one graph of 240,000 nodes in global numbering; the layers run as
-the persistent-rounds kernel k_gine_layer_q), as ``encode_graphs`` issues the micro-batches of
+the windowed rounds kernel k_gine_layer_w), as ``encode_graphs`` issues the micro-batches of
 one shard — with ``--streams`` batches in flight (default 2).  ``--batch 1`` is one shard per
 launch sequence (the one-round kernel k_gine_layer_f16).  K and W count SHARDS either way.
 Multi-GPU: shards are independent, every rank encodes its own shards, there is no data-path
@@ -28,7 +28,7 @@ than 10 ms (the driver's K=20 is 1.5 ms) the same leg is repeated until 10 ms ar
 reported beside the contract values (``timed_ms``, ``repeated``); ``value`` stays the K-step one.
 
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
-  roofline      dominant kernel (k_gine_layer_q, or k_gine_layer_f16 with --batch 1):
+  roofline      dominant kernel (k_gine_layer_w, or k_gine_layer_f16 with --batch 1):
                 algorithmic bytes per launch ((512·N + 9·E) x the shards of one launch + layer
                 weights) ÷ its mean duration IN THE
                 TIMED CONFIGURATION (all streams in flight), taken on the device clock by
@@ -509,7 +509,7 @@ def main() -> None:
         alone_call_ms = e0.elapsed_time(e1) / rounds
         plain = plain_layers(mean)
         one_round = full * NODES <= 256 * 8 * 32        # a CU gets at most one round of tiles
-        kernel_name = "k_gine_layer_f16" if one_round else "k_gine_layer_q"
+        kernel_name = "k_gine_layer_f16" if one_round else "k_gine_layer_w"
         roofline = {
             "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "kernel": kernel_name, "shards_per_launch": full,

@@ -19,6 +19,7 @@ GFY_L2, GFY_COSINE = 0, 1
 GFY_OPT_SEPARATE_HEAD = 2
 GFY_OPT_LAYER_KERNEL = 3
 GFY_OPT_STAGGER = 4
+GFY_OPT_PRIORITY = 6
 GFY_MAX_BATCH_SHARDS = 16
 GFY_TAP_H, GFY_TAP_Z, GFY_TAP_V, GFY_TAP_W, GFY_TAP_Y = 0, 1, 2, 3, 4
 ABI_VERSION = 3

@@ -470,9 +470,10 @@ int gfy_encoder_set_option(gfy_encoder* enc, int option, int value) {
       enc->separate_head = value;
       return GFY_OK;
     case GFY_OPT_LAYER_KERNEL:
-      GFY_REQUIRE(value == -1 || value == 1 || value == 3, GFY_ERR_INVALID,
+      GFY_REQUIRE(value == -1 || value == 1 || value == 3 || value == 4, GFY_ERR_INVALID,
                   "gfy_encoder_set_option: GFY_OPT_LAYER_KERNEL must be -1 (by rounds), 1 (round-2 "
-                  "kernel) or 3 (persistent rounds), got %d", value);
+                  "kernel), 3 (persistent rounds) or 4 (two windowed workgroups per CU), got %d",
+                  value);
       enc->layer_kernel = value;
       return GFY_OK;
     case GFY_OPT_STAGGER:
@@ -480,6 +481,12 @@ int gfy_encoder_set_option(gfy_encoder* enc, int option, int value) {
                   "gfy_encoder_set_option: GFY_OPT_STAGGER must be -1 (default) or 0..100000 "
                   "cycles (got %d)", value);
       enc->stagger = value;
+      return GFY_OK;
+    case GFY_OPT_PRIORITY:
+      GFY_REQUIRE(value >= -1 && value <= 63, GFY_ERR_INVALID,
+                  "gfy_encoder_set_option: GFY_OPT_PRIORITY must be -1 (default) or 0..63 (got %d)",
+                  value);
+      enc->priority = value;
       return GFY_OK;
     default:
       set_error("gfy_encoder_set_option: unknown option %d", option);

@@ -149,10 +149,11 @@ struct gfy_encoder {
   // 1 .. layers-1: an event between two dependent kernels costs ~2.5 us of stream time that
   // rocprof's kernel durations do not contain.
   int separate_head = 0;      // GFY_OPT_SEPARATE_HEAD
-  int layer_kernel = -1;      // GFY_OPT_LAYER_KERNEL: -1 by the launch's rounds, 1 round-2 kernel, 3 persistent rounds
+  int layer_kernel = -1;      // GFY_OPT_LAYER_KERNEL: -1 by the launch's rounds, 1 round-2 kernel, 3 persistent rounds, 4 windowed
   int cus = 256;              // compute units of the device (persistent grid)
   int stagger = -1;           // GFY_OPT_STAGGER: start offset between the workgroups of an XCD in
                               // shader cycles (persistent rounds); -1: 500 from three rounds up
+  int priority = -1;          // GFY_OPT_PRIORITY: windowed kernel, s_setprio levels (gine_layer_w.inc); -1: 4
   int timing = 0;
   // timing == 3: every layer launch records the device clock (s_memrealtime, 100 MHz) of its
   // first workgroup start and last workgroup end: the kernel's own duration, as a profiler

@@ -396,6 +396,7 @@ __global__ __launch_bounds__(256) void k_copy_rows_f16(const f16* __restrict__ s
 #include "csr_finish.inc"
 #include "gine_layer.inc"
 #include "gine_layer_q.inc"
+#include "gine_layer_w.inc"
 
 int persistent_grid(int num_tiles) {
   int g = num_tiles < 256 ? num_tiles : 256;
@@ -454,6 +455,11 @@ int prepare_device_f16() {   // gfy_encoder_create, with the encoder's device cu
     GFY_OPT_IN((k_gine_layer_q<false, false, true>), kQLdsBytes);
     GFY_OPT_IN((k_gine_layer_q<true, true, false>), kQLdsBytes);
     GFY_OPT_IN(k_head_d, kLdsBytes);
+    GFY_OPT_IN((k_gine_layer_w<true, false, false>), kWLdsBytes);
+    GFY_OPT_IN((k_gine_layer_w<false, false, false>), kWLdsBytes);
+    GFY_OPT_IN((k_gine_layer_w<true, false, true>), kWLdsBytes);
+    GFY_OPT_IN((k_gine_layer_w<false, false, true>), kWLdsBytes);
+    GFY_OPT_IN((k_gine_layer_w<true, true, false>), kWLdsBytes);
 #undef GFY_OPT_IN
     return GFY_OK;
   });
@@ -524,7 +530,19 @@ static int encode_f16_on(const gfy_encoder* enc, const ShardTable& shards, const
   const int wanted = (tiles_per_xcd + kLWaves - 1) / kLWaves, per_xcd = enc->cus / 8;
   const int p_grid = 8 * (wanted < per_xcd ? wanted : per_xcd);
   const int rounds = (wanted + per_xcd - 1) / per_xcd;
-  const bool persistent = enc->layer_kernel == 3 || (enc->layer_kernel < 0 && rounds > 1);
+  // ... and, where the edge table leaves its last rows free for the plan-head slots, as two
+  // 4-wave workgroups per CU with the weights streamed through a window (gine_layer_w.inc)
+  const bool window_ok = enc->edge_dim <= kWMaxEdgeTypes;
+  const bool windowed =
+      window_ok && (enc->layer_kernel == 4 || (enc->layer_kernel < 0 && rounds > 1));
+  const bool persistent =
+      !windowed && (enc->layer_kernel >= 3 || (enc->layer_kernel < 0 && rounds > 1));
+  const int w_wanted = (tiles_per_xcd + kWWaves - 1) / kWWaves, w_per_xcd = 2 * per_xcd;
+  const int w_grid = 8 * (w_wanted < w_per_xcd ? w_wanted : w_per_xcd);
+  const int w_rounds = (w_wanted + w_per_xcd - 1) / w_per_xcd;
+  const int w_stagger = enc->stagger >= 0 ? enc->stagger : w_rounds >= 3 ? 250 : 0;
+  // the second workgroup of a CU multiplies at s_setprio 1 (gine_layer_w.inc)
+  const int w_priority = enc->priority >= 0 ? enc->priority : 4;
   // start offsets only pay once a workgroup runs several rounds (the offset costs up to one
   // round at the start of the launch)
   const int stagger = enc->stagger >= 0 ? enc->stagger : rounds >= 3 ? 500 : 0;
@@ -552,7 +570,16 @@ static int encode_f16_on(const gfy_encoder* enc, const ShardTable& shards, const
   k_gine_layer_q<RES, false, HEAD><<<p_grid, kLThreads, kQLdsBytes, s>>>(                    \
       enc->f16.layer[l], ha, hb, csr_rows, csr_col, csr_typ, plans, csr_limit, layer_tiles,  \
       stagger, spent, span, kTapNone, nullptr, HEAD ? head_out : no_out)
-    if (persistent && enc->residual && with_head) GFY_LAUNCH_ROUNDS(true, true);
+#define GFY_LAUNCH_WINDOW(RES, HEAD)                                                         \
+  k_gine_layer_w<RES, false, HEAD><<<w_grid, kWThreads, kWLdsBytes, s>>>(                    \
+      enc->f16.layer[l], ha, hb, csr_rows, csr_col, csr_typ, plans, csr_limit, layer_tiles,  \
+      w_stagger, w_priority, spent, span, kTapNone, nullptr,         \
+      HEAD ? head_out : no_out)
+    if (windowed && enc->residual && with_head) GFY_LAUNCH_WINDOW(true, true);
+    else if (windowed && enc->residual) GFY_LAUNCH_WINDOW(true, false);
+    else if (windowed && with_head) GFY_LAUNCH_WINDOW(false, true);
+    else if (windowed) GFY_LAUNCH_WINDOW(false, false);
+    else if (persistent && enc->residual && with_head) GFY_LAUNCH_ROUNDS(true, true);
     else if (persistent && enc->residual) GFY_LAUNCH_ROUNDS(true, false);
     else if (persistent && with_head) GFY_LAUNCH_ROUNDS(false, true);
     else if (persistent) GFY_LAUNCH_ROUNDS(false, false);
@@ -562,6 +589,7 @@ static int encode_f16_on(const gfy_encoder* enc, const ShardTable& shards, const
     else GFY_LAUNCH_LAYER(false, false);
 #undef GFY_LAUNCH_LAYER
 #undef GFY_LAUNCH_ROUNDS
+#undef GFY_LAUNCH_WINDOW
     f16* sw = ha;
     ha = hb;
     hb = sw;
@@ -579,7 +607,7 @@ static int encode_f16_on(const gfy_encoder* enc, const ShardTable& shards, const
     GFY_CHECK_HIP(hipGetLastError());
     return GFY_OK;
   }
-  if (out_dtype == GFY_F16 && persistent) {
+  if (out_dtype == GFY_F16 && (persistent || windowed)) {
     k_head_d<<<p_grid, kLThreads, kLdsBytes, s>>>(enc->f16.head, ha, shards, layer_tiles,
                                                   normalise);
   } else {   // the tiled stand-alone head, shard by shard (f32 / f64 output, A/B runs)

@@ -250,12 +250,18 @@ int gfy_encoder_get_timing(gfy_encoder* encoder, float* ms_host, int capacity,
 /* Diagnostic options of one encoder (no reference counterpart; results within the stated
  * tolerances for every setting).  Set between encodes, never read from the environment.
  *   GFY_OPT_SEPARATE_HEAD  1: head + normalise as its own launch even for fp16 output
- *   GFY_OPT_LAYER_KERNEL   -1 (default): by the launch — persistent rounds when a CU gets more
- *                          than one round of eight 32-node tiles, else the one-round kernel whose
- *                          last launch carries the head; 1 / 3 force either
- *   GFY_OPT_STAGGER        persistent rounds: start offset between the workgroups of an XCD in
- *                          shader cycles; -1 (default): 500 from three rounds up, else 0          */
-enum gfy_option { GFY_OPT_SEPARATE_HEAD = 2, GFY_OPT_LAYER_KERNEL = 3, GFY_OPT_STAGGER = 4 };
+ *   GFY_OPT_LAYER_KERNEL   -1 (default): by the launch — several rounds of tiles per CU (a batch,
+ *                          a large micro-batch) run the windowed kernel (two 4-wave workgroups per
+ *                          CU, weights streamed; edge_dim <= 12, else persistent rounds), one
+ *                          round the one-round kernel whose last launch carries the head;
+ *                          1 / 3 / 4 force one-round / persistent rounds / windowed
+ *   GFY_OPT_STAGGER        rounds kernels: start offset between the workgroups of an XCD in
+ *                          shader cycles; -1 (default): 500 (windowed: 250) from three rounds up
+ *   GFY_OPT_PRIORITY       windowed kernel: s_setprio level of a CU's first (bits 1:0) / second
+ *                          (bits 3:2) workgroup while it multiplies, of the second one elsewhere
+ *                          (bits 5:4); -1 (default): 4                                            */
+enum gfy_option { GFY_OPT_SEPARATE_HEAD = 2, GFY_OPT_LAYER_KERNEL = 3, GFY_OPT_STAGGER = 4,
+                  GFY_OPT_PRIORITY = 6 };
 int gfy_encoder_set_option(gfy_encoder* encoder, int option, int value);
 
 /* ---- host (CPU) implementation --------------------------------------------------------

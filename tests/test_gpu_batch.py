@@ -48,7 +48,7 @@ def _single(engine, shard, out_dtype=torch.float16):
     return engine.encode_coo(x, ei, et, out_rows=rows, n_out=kept, out_dtype=out_dtype).cpu().numpy()
 
 
-@pytest.mark.parametrize("kernel", [-1, 1, 3])
+@pytest.mark.parametrize("kernel", [-1, 1, 3, 4])
 def test_batch_is_bit_identical_to_single_shards(gpu_encoder, mixed_shards, kernel):
     engine = gpu_encoder._engine
     try:
@@ -81,14 +81,16 @@ def test_batch_of_synthetic_shards_matches_the_reference_rows(gpu_encoder, golde
         assert outs[seed].cpu().numpy().tobytes() == _single(engine, shards[seed]).tobytes()
 
 
-def test_stand_alone_head_behind_persistent_rounds_gives_the_same_bytes(gpu_encoder, mixed_shards):
+@pytest.mark.parametrize("kernel", [3, 4])
+def test_stand_alone_head_behind_persistent_rounds_gives_the_same_bytes(gpu_encoder, mixed_shards,
+                                                                         kernel):
     """GFY_OPT_SEPARATE_HEAD: head + normalise as their own launch (k_head_d) behind the
     persistent-rounds layers instead of inside the last of them — the same pipeline on the
     same registers' worth of data, so the same bytes."""
     engine = gpu_encoder._engine
     inputs = [_device(engine, shard) for shard in mixed_shards]
     try:
-        engine.set_option(native.GFY_OPT_LAYER_KERNEL, 3)
+        engine.set_option(native.GFY_OPT_LAYER_KERNEL, kernel)
         fused = [o.cpu().numpy() for o in engine.encode_coo_batch(inputs)]
         engine.set_option(native.GFY_OPT_SEPARATE_HEAD, 1)
         apart = [o.cpu().numpy() for o in engine.encode_coo_batch(inputs)]

@@ -51,7 +51,9 @@ int main(int argc, char** argv) {
   const int layer_kernel = getenv("GFY_BENCH_LAYER_KERNEL") ? atoi(getenv("GFY_BENCH_LAYER_KERNEL")) : -1;
   GK(gfy_encoder_set_option(enc, GFY_OPT_LAYER_KERNEL, layer_kernel));
   const int stagger = getenv("GFY_BENCH_STAGGER") ? atoi(getenv("GFY_BENCH_STAGGER")) : -1;
-  GK(gfy_encoder_set_option(enc, GFY_OPT_STAGGER, stagger));   // 0 eight free-running waves, 1 round 2, 2 four waves
+  GK(gfy_encoder_set_option(enc, GFY_OPT_STAGGER, stagger));
+  const int prio = getenv("GFY_BENCH_PRIORITY") ? atoi(getenv("GFY_BENCH_PRIORITY")) : -1;
+  GK(gfy_encoder_set_option(enc, GFY_OPT_PRIORITY, prio));
   // graph: records of L nodes: backbone both ways, skip2 both ways, random matching both ways
   const int64_t recs = N / L;
   std::vector<int32_t> src, dst; std::vector<uint8_t> typ;
@@ -123,6 +125,7 @@ int main(int argc, char** argv) {
       GK(gfy_encoder_create(pack.data(), bytes, GFY_F16, 0, &encs[q])); CK(hipStreamCreateWithFlags(&ss[q], hipStreamNonBlocking));
       GK(gfy_encoder_set_option(encs[q], GFY_OPT_LAYER_KERNEL, layer_kernel));
       GK(gfy_encoder_set_option(encs[q], GFY_OPT_STAGGER, stagger));
+      GK(gfy_encoder_set_option(encs[q], GFY_OPT_PRIORITY, prio));
       CK(hipMalloc(&outs[q], N * 128 * 2)); CK(hipMalloc(&wb[q], b3)); CK(hipMemset(wb[q], 0, b3));
     }
     auto step = [&](int i) {
@@ -160,7 +163,28 @@ int main(int argc, char** argv) {
     gfy_debug_stamps(&st[0][0], 0);
     double sum[16] = {0};
     for (int b = 0; b < 256; ++b) for (int k = 0; k < 16; ++k) sum[k] += (double)st[b][k];
-    if (layer_kernel == 3 || (layer_kernel < 0 && N > 65536)) {
+    if (layer_kernel == 4) {   // two 4-wave workgroups per CU: first and second residents apart
+      const char* names[8] = {"prologue", "own rows + gather", "c0 | c1 + barrier", "products (4 barriers, c2, c3)",
+                              "head launch: LN..head pipeline", "head launch: stage DMA issue", "LayerNorm + store (head: LN)", "wait for the next stage (head: normalise + store + wait)"};
+      for (int half = 0; half < 2; ++half) {
+        double hs[16] = {0};
+        for (int b = 128 * half; b < 128 * (half + 1); ++b) for (int k = 0; k < 16; ++k) hs[k] += (double)st[b][k];
+        const double rounds = hs[11] > 0 ? hs[11] : 1;
+        printf("windowed layer kernel, %s workgroups of the CUs, shader cycles per round (wave %d):\n", half ? "SECOND" : "FIRST", 0);
+        for (int k = 1; k < 8; ++k) printf("  %-56s %8.0f\n", names[k], hs[k] / rounds);
+        printf("  inside the products, waits at step 12 / 28 / 44 / 60, stage DMA issue: %.0f %.0f %.0f %.0f %.0f\n",
+               hs[8] / rounds, hs[9] / rounds, hs[12] / rounds, hs[13] / rounds, (hs[14] - hs[13]) / rounds);
+        printf("  rounds per workgroup and launch %.2f, whole wave %.0f cycles per launch, %.0f per round\n",
+               rounds / (128.0 * reps * 4), hs[10] / (128.0 * reps * 4), hs[10] / rounds);
+      }
+      static unsigned long long real[512][2];
+      gfy_debug_real(&real[0][0]);
+      double life = 0; int used = 0;
+      for (int b = 0; b < 512; ++b)
+        if (real[b][1] > real[b][0]) life += (real[b][1] - real[b][0]) / 100.0, ++used;
+      if (used) printf("  last launch: workgroup lifetime %.1f us (mean of %d) -> %.2f GHz\n", life / used, used,
+                       sum[10] / (256.0 * reps * 4) / (life / used) / 1e3);
+    } else if (layer_kernel >= 3 || (layer_kernel < 0 && N > 65536)) {
       const double rounds = sum[11] > 0 ? sum[11] : 1;
       const char* names[8] = {"prologue (image, first plan head + stage)", "own rows + gather",
                               "[W0 | W1] over the stages + barrier", "update MLP (both products)",
