@@ -71,6 +71,7 @@ SIGNATURES: dict[str, tuple] = {
                                 c_int64, c_int64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "gfy_encoder_set_timing": (c_int, [c_void_p, c_int]),
     "gfy_encoder_set_option": (c_int, [c_void_p, c_int, c_int]),
+    "gfy_encoder_last_layer_kernel": (c_int, [c_void_p]),
     "gfy_encoder_get_timing": (c_int, [c_void_p, c_void_p, c_int,
                                        POINTER(c_int)]),
     "gfy_pairwise_dense": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int,

@@ -113,6 +113,30 @@ def _advise_huge_pages(block: np.ndarray) -> None:
         pass
 
 
+#: consecutive micro-batches of a call that share one sequence of launches
+#: (``gfy_encode_coo_batch``, at most 16): four 60,000-node micro-batches give every CU 3.7
+#: rounds of tiles, and a group's embeddings (61 MB) come back as one copy
+MICROBATCH_GROUP = 4
+
+
+def _groups(count: int, size: int | None = None) -> list[range]:
+    size = MICROBATCH_GROUP if size is None else size
+    return [range(first, min(first + size, count)) for first in range(0, count, size)]
+
+
+def _settle(jobs) -> None:
+    """A call is leaving through an exception: no helper job of it may run (and write into a
+    staging slot the next call could be handed) after that."""
+    for job in jobs:
+        job.cancel()
+    for job in jobs:
+        if not job.cancelled():
+            try:
+                job.exception()
+            except BaseException:       # pragma: no cover - cancelled meanwhile
+                pass
+
+
 #: default mode only: results alive beyond this many page-locked bytes go to pageable memory
 PINNED_RESULT_LIMIT = 4 << 30
 _pinned_alive = [0]                     # bytes of page-locked result blocks not yet dropped
@@ -221,6 +245,8 @@ class _DirectDownloader:
 
         def result(self) -> None:
             self._owner._pump(until=self)
+            if self._done is None:
+                raise RuntimeError("this copy was abandoned (the call that queued it raised)")
             self._done.synchronize()
 
     def __init__(self, device: torch.device) -> None:
@@ -496,29 +522,44 @@ class Ginfinity:
             self._preparer = ThreadPoolExecutor(max_workers=6,
                                                 thread_name_prefix="ginfinity-prep")
         columns_of = [self._preparer.submit(text.positional, a, b) for a, b in bounds]
-        for (start, stop), columns_job in zip(bounds, columns_of):
-            n0, n1 = int(text.node_ptr[start]), int(text.node_ptr[stop])
-            e0, e1 = int(text.edge_ptr[start]), int(text.edge_ptr[stop])
-            columns = columns_job.result()
-            packed = self._uploader.pack(self._uploader.reserve(), (
-                text.bases[n0:n1], text.marks[n0:n1], text.node_ptr[start:stop + 1],
-                text.edge_ptr[start:stop + 1], columns))
-            bases, marks, node_ptr, edge_ptr, positional = self._uploader.send(packed,
-                                                                               mapped=direct)
-            features, edge_index, edge_types, first_invalid = engine.build_graphs(
-                bases, marks, node_ptr, edge_ptr, positional, n1 - n0, e1 - e0,
-                struct_states=1 if spec.struct_feature == "A" else 3,
-                skip2=spec.has_skip2)
-            row = n0 - int(text.node_ptr[0])
-            block = engine.encode_coo(features, edge_index, edge_types, out_dtype=torch_dtype,
-                                      normalise=True, out=device_rows[row:row + n1 - n0])
-            ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream(device))
-            if direct:
-                self._uploader.hold(packed, ready)
-            verdicts.append((start, first_invalid))
-            pending.append((fetch(block, ready, row, n1 - n0),
-                            row, n1 - n0, lengths[start:stop]))
+        assert MICROBATCH_GROUP <= self._uploader.slots   # a group's inputs live in the ring
+        try:
+            for group in _groups(len(bounds)):
+                members, group_row = [], None
+                for index in group:
+                    start, stop = bounds[index]
+                    n0, n1 = int(text.node_ptr[start]), int(text.node_ptr[stop])
+                    e0, e1 = int(text.edge_ptr[start]), int(text.edge_ptr[stop])
+                    columns = columns_of[index].result()
+                    packed = self._uploader.pack(self._uploader.reserve(), (
+                        text.bases[n0:n1], text.marks[n0:n1], text.node_ptr[start:stop + 1],
+                        text.edge_ptr[start:stop + 1], columns))
+                    bases, marks, node_ptr, edge_ptr, positional = self._uploader.send(
+                        packed, mapped=direct)
+                    features, edge_index, edge_types, first_invalid = engine.build_graphs(
+                        bases, marks, node_ptr, edge_ptr, positional, n1 - n0, e1 - e0,
+                        struct_states=1 if spec.struct_feature == "A" else 3,
+                        skip2=spec.has_skip2)
+                    row = n0 - int(text.node_ptr[0])
+                    group_row = row if group_row is None else group_row
+                    members.append((packed, (features, edge_index, edge_types, None,
+                                             device_rows[row:row + n1 - n0])))
+                    verdicts.append((start, first_invalid))
+                    pending.append((row, n1 - n0, lengths[start:stop]))
+                engine.encode_coo_group([tensors for _packed, tensors in members])
+                ready = torch.cuda.Event()
+                ready.record(torch.cuda.current_stream(device))
+                if direct:
+                    for packed, _tensors in members:
+                        self._uploader.hold(packed, ready)
+                last_row, last_kept, _counts = pending[-1]
+                landing = fetch(device_rows[group_row:last_row + last_kept], ready, group_row,
+                                last_row + last_kept - group_row)
+                for slot in range(len(pending) - len(members), len(pending)):
+                    pending[slot] = (landing,) + pending[slot]
+        except BaseException:
+            _settle(columns_of)
+            raise
         outputs: list[np.ndarray] = []
         for job, row, kept, counts in pending:     # views cut here, as the copies land
             job.result()
@@ -618,31 +659,48 @@ class Ginfinity:
                 shard.edge_types[e0:e1], rows))
             return packed, kept
 
-        ahead = max(1, uploader.slots - 1)
+        assert MICROBATCH_GROUP <= uploader.slots
         jobs: list = []
         pending = []
         first_row = 0
-        for index, (start, stop) in enumerate(bounds):
-            while len(jobs) < len(bounds) and len(jobs) <= index + ahead - 1:
-                a, b = bounds[len(jobs)]
-                jobs.append(self._preparer.submit(prepare, uploader.reserve(), a, b))
-            packed, kept = jobs[index].result()
-            features, edge_index, edge_types, out_rows = uploader.send(packed, mapped=direct)
-            block = self._engine.encode_coo(features, edge_index, edge_types,
-                                            out_rows=out_rows, n_out=kept,
-                                            out_dtype=torch_dtype, normalise=True,
-                                            out=device_rows[first_row:first_row + kept])
-            ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream(self._engine.device))
-            if direct:
-                uploader.hold(packed, ready)
-            # (the workers run no interpreter-level loops: a worker cutting 400 views holds the
-            # GIL for 0.3 ms at a time and this thread, which needs it between every two
-            # enqueues, took 0.6 ms per micro-batch instead of 0.1)
-            pending.append((fetch(block, ready, first_row, kept),
-                            first_row, kept, core_counts[start:stop]))
-            first_row += kept
-        # the per-record views are cut here, micro-batch by micro-batch as the copies land
+        try:
+            for group in _groups(len(bounds)):
+                # the micro-batches of a group share every launch (gfy_encode_coo_batch): a
+                # 60,000-node micro-batch by itself gives a CU less than one round of tiles
+                members, group_row = [], first_row
+                # packers run ahead of this thread, but never into a staging slot whose last
+                # user has not been launched: a slot is guarded by the event of the GROUP that
+                # read it (`hold`, below), so micro-batch j may be packed once micro-batch
+                # j - slots belongs to a group in front of this one
+                while len(jobs) < len(bounds) and len(jobs) < group.start + uploader.slots:
+                    a, b = bounds[len(jobs)]
+                    jobs.append(self._preparer.submit(prepare, uploader.reserve(), a, b))
+                for index in group:
+                    packed, kept = jobs[index].result()
+                    features, edge_index, edge_types, out_rows = uploader.send(packed,
+                                                                               mapped=direct)
+                    members.append((packed, (features, edge_index, edge_types, out_rows,
+                                             device_rows[first_row:first_row + kept])))
+                    start, stop = bounds[index]
+                    pending.append((first_row, kept, core_counts[start:stop]))
+                    first_row += kept
+                self._engine.encode_coo_group([tensors for _packed, tensors in members])
+                ready = torch.cuda.Event()
+                ready.record(torch.cuda.current_stream(self._engine.device))
+                if direct:
+                    for packed, _tensors in members:
+                        uploader.hold(packed, ready)
+                # (the workers run no interpreter-level loops: a worker cutting 400 views holds
+                # the GIL for 0.3 ms at a time and this thread, which needs it between every two
+                # enqueues, took 0.6 ms per micro-batch instead of 0.1)
+                landing = fetch(device_rows[group_row:first_row], ready, group_row,
+                                first_row - group_row)
+                for slot in range(len(pending) - len(members), len(pending)):
+                    pending[slot] = (landing,) + pending[slot]
+        except BaseException:
+            _settle(jobs)      # no packer may still be writing a staging slot after we leave
+            raise
+        # the per-record views are cut here, group by group as the copies land
         outputs: list[np.ndarray] = []
         for job, row, kept, counts in pending:
             job.result()
@@ -724,25 +782,76 @@ class Ginfinity:
         block = self._encode_shard_device(shard, torch_dtype).cpu().numpy()
         return self._splitter(shard.core_counts, embedding_dtype, exact)(block)
 
+    # -- device-resident results (MI355X-side extension; no reference counterpart) ----------
+    def stage_shards(self, shards: "GraphShard | Sequence[GraphShard]", *,
+                     max_batch_nodes: int = 60_000, max_batch_edges: int = 300_000
+                     ) -> tuple[list[tuple], list[tuple[int, ...]]]:
+        """Upload the micro-batches of one shard or of several: ``(staged, counts)`` — the
+        device arrays of every micro-batch, in order (the input of ``encode_staged``), and
+        the per-record core row counts of every shard.  Same packing, limits and errors as
+        ``encode_graphs`` (api.py:196-230), the slices validated as the reference validates
+        them (``GraphShard.slice``)."""
+        if self._engine is None:
+            raise ValueError("device-resident encoding needs a GPU encoder (device='cuda')")
+        if isinstance(shards, GraphShard):
+            shards = [shards]
+        staged: list[tuple] = []
+        counts: list[tuple[int, ...]] = []
+        for shard in shards:
+            shard = self._checked_shard(shard, max_batch_nodes, max_batch_edges)
+            counts.append(shard.core_counts)
+            for a, b in microbatch_bounds(shard.lengths, shard.edge_counts,
+                                          max_batch_nodes, max_batch_edges):
+                piece = shard if (a, b) == (0, shard.record_count) else shard.slice(a, b)
+                staged.append(self._engine.upload_arrays(
+                    piece.node_features, piece.edge_index, piece.edge_types, piece.node_roles))
+        return staged, counts
+
+    def encode_staged(self, staged: Sequence[tuple], *,
+                      out: torch.Tensor | None = None) -> torch.Tensor:
+        """fp16 embeddings of staged micro-batches as ONE device tensor ([total core rows, 128]),
+        the micro-batches issued in groups of ``MICROBATCH_GROUP`` through
+        ``gfy_encode_coo_batch`` — nothing crosses PCIe, nothing returns to the host.  ``out``:
+        a tensor of that shape to write into (steady-state loops: no allocation per call)."""
+        if self._engine is None:
+            raise ValueError("device-resident encoding needs a GPU encoder (device='cuda')")
+        rows = sum(kept for *_arrays, kept in staged)
+        block = out
+        if block is None:
+            block = torch.empty((rows, self.embedding_dimension), dtype=torch.float16,
+                                device=self._engine.device)
+        if (tuple(block.shape) != (rows, self.embedding_dimension)
+                or block.dtype != torch.float16 or not block.is_contiguous()):
+            raise ValueError("out must be a contiguous float16 [total core rows, 128] tensor")
+        first = 0
+        for group in _groups(len(staged)):
+            members = []
+            for index in group:
+                features, edge_index, edge_types, out_rows, kept = staged[index]
+                members.append((features, edge_index, edge_types, out_rows,
+                                block[first:first + kept]))
+                first += kept
+            self._engine.encode_coo_group(members)
+        return block
+
+    def encode_shards_device(self, shards: Sequence[GraphShard], *,
+                             max_batch_nodes: int = 60_000, max_batch_edges: int = 300_000
+                             ) -> tuple[torch.Tensor, list[tuple[int, ...]]]:
+        """Several shards → one device block of all their core rows (shard after shard) and
+        the per-record row counts of every shard: what a rank of ``parallel`` encodes."""
+        staged, counts = self.stage_shards(shards, max_batch_nodes=max_batch_nodes,
+                                           max_batch_edges=max_batch_edges)
+        return self.encode_staged(staged), counts
+
     def encode_graphs_device(self, shard: GraphShard, *,
                              max_batch_nodes: int = 60_000,
                              max_batch_edges: int = 300_000
                              ) -> tuple[torch.Tensor, tuple[int, ...]]:
-        """MI355X-side extension: fp16 embeddings of the whole shard as ONE
-        device tensor ([total core nodes, 128]) plus the per-record row counts —
-        the input format of ``ginfinity_amd.distance``; nothing returns to
-        the host."""
-        if self._engine is None:
-            raise ValueError("encode_graphs_device needs a GPU encoder (device='cuda')")
-        shard = self._checked_shard(shard, max_batch_nodes, max_batch_edges)
-        pieces = [
-            self._encode_shard_device(
-                shard if (a, b) == (0, shard.record_count) else shard.slice(a, b),
-                torch.float16)
-            for a, b in microbatch_bounds(shard.lengths, shard.edge_counts,
-                                          max_batch_nodes, max_batch_edges)]
-        block = pieces[0] if len(pieces) == 1 else torch.cat(pieces, dim=0)
-        return block, shard.core_counts
+        """fp16 embeddings of the whole shard as ONE device tensor ([total core nodes, 128])
+        plus the per-record row counts — the input format of ``ginfinity_amd.distance``."""
+        block, counts = self.encode_shards_device([shard], max_batch_nodes=max_batch_nodes,
+                                                  max_batch_edges=max_batch_edges)
+        return block, counts[0]
 
 
 __all__ = ["Ginfinity", "ModelIntegrityError", "default_alignment_parameters",

@@ -494,6 +494,10 @@ int gfy_encoder_set_option(gfy_encoder* enc, int option, int value) {
   }
 }
 
+int gfy_encoder_last_layer_kernel(const gfy_encoder* enc) {
+  return enc ? enc->last_layer_kernel : 0;
+}
+
 int gfy_encoder_get_timing(gfy_encoder* enc, float* ms_host, int capacity, int* count) {
   clear_error();
   GFY_REQUIRE(enc && ms_host && count, GFY_ERR_INVALID, "gfy_encoder_get_timing: NULL argument");

@@ -160,6 +160,7 @@ struct gfy_encoder {
   // sees it, also when other streams keep the chip busy between two events of this one
   unsigned long long* device_spans = nullptr;   // [kMaxLayers][2] on the device
   mutable hipStream_t last_stream = nullptr;    // stream of the last encode (get_timing waits on it)
+  mutable int last_layer_kernel = 0;            // layer kernel the last fp16 encode launched (1 / 3 / 4)
   hipEvent_t events[gfy::kMaxLayers + 3] = {};
   mutable int events_recorded = 0;
   void mark(hipStream_t s, int slot) const {

@@ -540,6 +540,7 @@ static int encode_f16_on(const gfy_encoder* enc, const ShardTable& shards, const
   const int w_wanted = (tiles_per_xcd + kWWaves - 1) / kWWaves, w_per_xcd = 2 * per_xcd;
   const int w_grid = 8 * (w_wanted < w_per_xcd ? w_wanted : w_per_xcd);
   const int w_rounds = (w_wanted + w_per_xcd - 1) / w_per_xcd;
+  enc->last_layer_kernel = windowed ? 4 : persistent ? 3 : 1;
   const int w_stagger = enc->stagger >= 0 ? enc->stagger : w_rounds >= 3 ? 250 : 0;
   // the second workgroup of a CU multiplies at s_setprio 1 (gine_layer_w.inc)
   const int w_priority = enc->priority >= 0 ? enc->priority : 4;

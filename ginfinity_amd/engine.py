@@ -188,6 +188,34 @@ class DeviceEncoder:
                 _ptr(scratch), scratch.numel(), self._stream()), "gfy_encode")
         return out
 
+    def _coo_scratch(self, need: int, rows: int, stream) -> torch.Tensor:
+        """The encoder's ONE workspace of ``gfy_encode_coo`` / ``gfy_encode_coo_batch`` calls,
+        with its leading counters zero for a call over ``rows`` padded rows (include/gfy.h: they
+        are zero again after every call, so only a call LARGER than every call since the last
+        clearing finds other arrays where its counters will be), and ordered behind the last
+        call when that ran on another stream."""
+        if self._coo_workspace is None or self._coo_workspace.numel() < need:
+            self._coo_workspace = torch.zeros(max(need, 1 << 20), dtype=torch.uint8,
+                                              device=self.device)
+            self._coo_clean_nodes = 1 << 62
+            self._coo_done, self._coo_stream = None, None   # zero-filled on THIS stream
+        elif self._coo_stream is not None and self._coo_stream != stream.cuda_stream:
+            stream.wait_event(self._coo_done)     # the last call ran on another stream
+        scratch = self._coo_workspace
+        if rows > self._coo_clean_nodes:
+            native.check(self._lib.gfy_encode_coo_prepare(
+                _ptr(scratch), scratch.numel(), rows, stream.cuda_stream),
+                "gfy_encode_coo_prepare")
+        self._coo_clean_nodes = 0               # until the call has been enqueued
+        return scratch
+
+    def _coo_enqueued(self, rows: int, stream) -> None:
+        self._coo_clean_nodes = rows
+        if self._coo_done is None:
+            self._coo_done = torch.cuda.Event()
+        self._coo_done.record(stream)
+        self._coo_stream = stream.cuda_stream
+
     def encode_coo(self, node_features: torch.Tensor, edge_index: torch.Tensor,
                    edge_types: torch.Tensor, *, out_rows: torch.Tensor | None = None,
                    n_out: int | None = None, out_dtype: torch.dtype = torch.float16,
@@ -209,29 +237,13 @@ class DeviceEncoder:
             assert out.is_contiguous() and out.shape == (rows, EMBEDDING_DIM)
             need = lib.gfy_encode_coo_workspace_bytes(self._handle, nodes, edges)
             stream = torch.cuda.current_stream(self.device)
-            if self._coo_workspace is None or self._coo_workspace.numel() < need:
-                self._coo_workspace = torch.zeros(max(need, 1 << 20), dtype=torch.uint8,
-                                                  device=self.device)
-                self._coo_clean_nodes = 1 << 62
-                self._coo_done, self._coo_stream = None, None   # zero-filled on THIS stream
-            elif self._coo_stream is not None and self._coo_stream != stream.cuda_stream:
-                stream.wait_event(self._coo_done)     # the last call ran on another stream
-            scratch = self._coo_workspace
-            if nodes > self._coo_clean_nodes:   # an earlier, smaller call's arrays lie where
-                native.check(lib.gfy_encode_coo_prepare(   # this call's counters will be
-                    _ptr(scratch), scratch.numel(), nodes, stream.cuda_stream),
-                    "gfy_encode_coo_prepare")
-            self._coo_clean_nodes = 0           # until the call below has been enqueued
+            scratch = self._coo_scratch(need, -(-nodes // 32) * 32, stream)
             native.check(lib.gfy_encode_coo(
                 self._handle, _ptr(node_features), _ptr(edge_index) if edges else None,
                 _ptr(edge_types) if edges else None, nodes, edges, _ptr(out_rows), _ptr(out),
                 _GFY_OF_TORCH[out.dtype], 1 if normalise else 0, _ptr(scratch),
                 scratch.numel(), stream.cuda_stream), "gfy_encode_coo")
-            self._coo_clean_nodes = nodes
-            if self._coo_done is None:
-                self._coo_done = torch.cuda.Event()
-            self._coo_done.record(stream)
-            self._coo_stream = stream.cuda_stream
+            self._coo_enqueued(-(-nodes // 32) * 32, stream)
         return out
 
     def prepare_step(self, node_features: torch.Tensor, edge_index: torch.Tensor,
@@ -334,6 +346,29 @@ class DeviceEncoder:
             step(self._stream())
         return outs
 
+    def encode_coo_group(self, shards, *, normalise: bool = True) -> None:
+        """Up to 16 micro-batches in ONE sequence of launches (``gfy_encode_coo_batch``) on the
+        current stream and on the encoder's own workspace: what ``encode_graphs`` issues for a
+        group of consecutive micro-batches (reference: the micro-batch loop api.py:211-230).
+        ``shards``: (node_features, edge_index, edge_types, out_rows or None, out) device
+        tensors, every ``out`` preallocated ([n_out, 128], one dtype)."""
+        array = self._shard_array(shards)
+        count = len(shards)
+        out_code = _GFY_OF_TORCH[shards[0][4].dtype]
+        assert all(s[4].dtype == shards[0][4].dtype for s in shards)
+        lib = self._lib
+        with torch.cuda.device(self.device):
+            need = lib.gfy_encode_coo_batch_workspace_bytes(self._handle, array, count)
+            if need == 0:
+                native.check(native.GFY_ERR_INVALID, "gfy_encode_coo_batch_workspace_bytes")
+            rows = sum(-(-int(x.shape[0]) // 32) * 32 for x, *_rest in shards)
+            stream = torch.cuda.current_stream(self.device)
+            scratch = self._coo_scratch(need, rows, stream)
+            native.check(lib.gfy_encode_coo_batch(
+                self._handle, array, count, out_code, 1 if normalise else 0, _ptr(scratch),
+                scratch.numel(), stream.cuda_stream), "gfy_encode_coo_batch")
+            self._coo_enqueued(rows, stream)
+
     def hidden(self, node_features: torch.Tensor, csr: DeviceCsr,
                stage: int) -> torch.Tensor:
         """Parity tap: hidden state after ``stage`` (0 = input Linear,
@@ -377,6 +412,11 @@ class DeviceEncoder:
         native.check(self._lib.gfy_encoder_set_option(
             self._handle, int(option), int(value)), "gfy_encoder_set_option")
 
+    def last_layer_kernel(self) -> int:
+        """Layer kernel of the last fp16-model encode (``native.GFY_OPT_LAYER_KERNEL`` values:
+        1 one round per launch, 3 persistent rounds, 4 windowed rounds; 0: none yet)."""
+        return int(self._lib.gfy_encoder_last_layer_kernel(self._handle))
+
     def set_timing(self, enabled: bool | int) -> None:
         """True / 1: an event after every launch; 2: none between layer launches
         1 .. L-1, whose mean is reported (agrees with rocprof's kernel durations for one
@@ -405,6 +445,23 @@ class DeviceEncoder:
             warnings.filterwarnings("ignore", message="The given NumPy array is not writable")
             return torch.from_numpy(np.ascontiguousarray(array)).to(self.device)
 
+    def upload_arrays(self, node_features: np.ndarray, edge_index: np.ndarray,
+                      edge_types: np.ndarray, node_roles: np.ndarray | None) -> tuple:
+        """Host arrays of one micro-batch → ``(features, edge_index, edge_types, out_rows or
+        None, kept)`` on the device: context nodes (role != 0) take part in message passing
+        and are dropped at the head's store through ``out_rows`` (api.py:253-260)."""
+        nodes = int(node_features.shape[0])
+        out_rows, kept = None, nodes
+        if node_roles is not None:
+            core = node_roles == 0
+            kept = int(np.count_nonzero(core))
+            if kept != nodes:
+                rows = np.cumsum(core, dtype=np.int32) - np.int32(1)
+                rows[~core] = -1
+                out_rows = torch.from_numpy(rows).to(self.device)
+        x, ei, et = (self._upload(a) for a in (node_features, edge_index, edge_types))
+        return x, ei, et, out_rows, kept
+
     def encode_arrays(self, node_features: np.ndarray, edge_index: np.ndarray,
                       edge_types: np.ndarray, node_roles: np.ndarray | None,
                       *, out_dtype: torch.dtype = torch.float16,
@@ -413,16 +470,7 @@ class DeviceEncoder:
         """Host arrays of one shard slice → [core_nodes, 128] device tensor.
         Context nodes (role != 0) take part in message passing and are dropped
         in the head kernel's store (api.py:253-260)."""
-        nodes = int(node_features.shape[0])
-        out_rows = None
-        n_out = nodes
-        if node_roles is not None:
-            core = node_roles == 0
-            n_out = int(np.count_nonzero(core))
-            if n_out != nodes:
-                rows = np.cumsum(core, dtype=np.int32) - np.int32(1)
-                rows[~core] = -1
-                out_rows = torch.from_numpy(rows).to(self.device)
-        x, ei, et = (self._upload(a) for a in (node_features, edge_index, edge_types))
+        x, ei, et, out_rows, n_out = self.upload_arrays(node_features, edge_index, edge_types,
+                                                        node_roles)
         return self.encode_coo(x, ei, et, out_rows=out_rows, n_out=n_out,
                                out_dtype=out_dtype, normalise=normalise, out=out)

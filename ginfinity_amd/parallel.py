@@ -49,16 +49,12 @@ def encode_owned_shards(encoder, shards: Sequence, *, group=None,
     per-shard per-record row counts)."""
     rank, size = world(group)
     owned = shard_assignment(len(shards), size, rank)
-    blocks, counts = [], []
-    for index in owned:
-        block, per_record = encoder.encode_graphs_device(
-            shards[index], max_batch_nodes=max_batch_nodes,
+    if owned:   # all owned shards in one call: their micro-batches share launches in groups
+        merged, counts = encoder.encode_shards_device(
+            [shards[index] for index in owned], max_batch_nodes=max_batch_nodes,
             max_batch_edges=max_batch_edges)
-        blocks.append(block)
-        counts.append(per_record)
-    if blocks:
-        merged = blocks[0] if len(blocks) == 1 else torch.cat(blocks, dim=0)
     else:
+        counts = []
         merged = torch.empty((0, 128), dtype=torch.float16,
                              device=encoder._engine.device)
     return merged, owned, counts

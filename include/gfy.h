@@ -263,6 +263,10 @@ int gfy_encoder_get_timing(gfy_encoder* encoder, float* ms_host, int capacity,
 enum gfy_option { GFY_OPT_SEPARATE_HEAD = 2, GFY_OPT_LAYER_KERNEL = 3, GFY_OPT_STAGGER = 4,
                   GFY_OPT_PRIORITY = 6 };
 int gfy_encoder_set_option(gfy_encoder* encoder, int option, int value);
+/* Which layer kernel the encoder's last fp16-model encode launched (the values of
+ * GFY_OPT_LAYER_KERNEL: 1 one round, 3 persistent rounds, 4 windowed; 0: none yet): lets a
+ * caller — and the tests — see that a call took the batched path. */
+int gfy_encoder_last_layer_kernel(const gfy_encoder* encoder);
 
 /* ---- host (CPU) implementation --------------------------------------------------------
  * The reference's default device is the CPU (api.py:64-76: Ginfinity.load(device="cpu")); these

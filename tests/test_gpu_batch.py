@@ -154,3 +154,48 @@ def test_batch_argument_errors(gpu_encoder, mixed_shards):
     array = (native.GfyShard * 1)()
     assert lib.gfy_encode_coo_batch(engine._handle, array, 1, native.GFY_F16, 1, None, 0,
                                     None) == native.GFY_ERR_INVALID
+
+
+def test_encode_graphs_issues_its_micro_batches_in_groups(gpu_encoder, golden, rouskin_shard,
+                                                          monkeypatch):
+    """The product path is the measured path: ``encode_graphs`` on the 897,588-node shard (15
+    micro-batches, reference loop api.py:211-230) hands groups of four micro-batches to
+    ``gfy_encode_coo_batch`` — the launches then run the rounds kernel, not the one-round
+    kernel of a lone 60,000-node micro-batch — and gives the bytes the micro-batch-by-micro-batch
+    path gives, within 1e-3 of the reference's own rows."""
+    from ginfinity_amd import api
+    engine = gpu_encoder._engine
+    assert api.MICROBATCH_GROUP == 4
+    grouped = np.concatenate(gpu_encoder.encode_graphs(rouskin_shard))
+    assert engine.last_layer_kernel() == 4          # windowed rounds (gine_layer_w.inc)
+    g = golden("rouskin_full.npz")
+    sampled = grouped[::int(g["stride"])].astype(np.float64)
+    assert np.abs(sampled - g["rows"].astype(np.float64)).max() <= 1e-3
+    monkeypatch.setattr(api, "MICROBATCH_GROUP", 1)
+    single = np.concatenate(gpu_encoder.encode_graphs(rouskin_shard))
+    assert engine.last_layer_kernel() == 1          # a 60,000-node launch: one round per CU
+    assert grouped.tobytes() == single.tobytes()
+    monkeypatch.setattr(api, "MICROBATCH_GROUP", 3)  # ragged groups: 3 x 5
+    assert np.concatenate(gpu_encoder.encode_graphs(rouskin_shard)).tobytes() == single.tobytes()
+
+
+def test_records_and_device_blocks_take_the_grouped_path_too(gpu_encoder, rouskin_records,
+                                                             rouskin_shard, monkeypatch):
+    """``encode_many`` from text (graphs built on the device) and ``encode_graphs_device`` /
+    ``encode_shards_device`` (what ``parallel.encode_owned_shards`` calls) issue the same
+    groups; every one of them equals the micro-batch-by-micro-batch result bit for bit."""
+    from ginfinity_amd import api
+    engine = gpu_encoder._engine
+    records = rouskin_records[:1500]                 # ~230,000 nodes: 4 micro-batches
+    shard = rouskin_shard.slice(0, 1500)
+    grouped = np.concatenate(gpu_encoder.encode_many(records))
+    assert engine.last_layer_kernel() == 4
+    block, counts = gpu_encoder.encode_graphs_device(shard)
+    assert engine.last_layer_kernel() == 4
+    blocks, many = gpu_encoder.encode_shards_device([shard.slice(0, 700), shard.slice(700, 1500)])
+    monkeypatch.setattr(api, "MICROBATCH_GROUP", 1)
+    single = np.concatenate(gpu_encoder.encode_many(records))
+    assert grouped.tobytes() == single.tobytes()
+    assert block.cpu().numpy().tobytes() == single.tobytes()
+    assert blocks.cpu().numpy().tobytes() == single.tobytes()
+    assert counts == shard.core_counts and list(map(len, many)) == [700, 800]

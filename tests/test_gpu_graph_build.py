@@ -4,6 +4,8 @@ and the encode_many path that uses it against encode_graphs on host-built shards
 from __future__ import annotations
 
 import hashlib
+import json
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -205,3 +207,64 @@ def test_cli_embed_and_embed_graphs_write_the_reference_archives(tmp_path, capsy
         for record, expected in zip(records, want):
             assert a[record.identifier].tobytes() == expected.tobytes()
             assert b[record.identifier].tobytes() == expected.tobytes()
+
+
+# ---- f3 on the GPU against the files the REFERENCE wrote (tests/golden/io, make_io_golden.py) ----
+IO = Path(__file__).resolve().parent / "golden" / "io"
+
+
+def _archives_agree(ours_path, reference_path, tolerance=1e-3):
+    with np.load(ours_path) as ours, np.load(reference_path) as theirs:
+        assert list(ours.files) == list(theirs.files)
+        for key in theirs.files:
+            assert ours[key].shape == theirs[key].shape and ours[key].dtype == theirs[key].dtype
+            worst = np.abs(ours[key].astype(np.float64) - theirs[key].astype(np.float64)).max()
+            assert worst <= tolerance, (key, worst)
+
+
+def _manifests_agree(ours_path, reference_path, *, device):
+    mine = json.loads(Path(ours_path).read_text())
+    reference = json.loads(Path(reference_path).read_text())
+    assert set(mine) == set(reference)
+    assert mine["device"] == device and mine["status"] == "complete"
+    assert [set(r) for r in mine["records"]] == [set(r) for r in reference["records"]]
+    for a, b in zip(mine["records"], reference["records"]):
+        assert ({k: a[k] for k in a if "sha256" not in k}
+                == {k: b[k] for k in b if "sha256" not in k})
+    return mine, reference
+
+
+def test_cli_embed_graphs_on_the_gpu_from_the_reference_s_shard(tmp_path, capsys):
+    """``ginfinity embed-graphs --device cuda`` on the shard file the REFERENCE's
+    ``build-graphs`` wrote (graph.py:756-823; loaded with checksum and full validation,
+    graph.py:826-923) against the archive and manifest the reference's ``embed-graphs`` wrote
+    (cli.py:138-197): members within 1e-3, same manifest keys and per-record entries."""
+    from ginfinity_amd import cli
+    out = tmp_path / "graphs.npz"
+    assert cli.main(["embed-graphs", "--input", str(IO / "ref_shard.safetensors"),
+                     "--output", str(out), "--verify-checksum", "--full-validation",
+                     "--checksum", "--device", "cuda", "--allow-nondeterministic-cuda"]) == 0
+    capsys.readouterr()
+    _archives_agree(out, IO / "ref_embed_graphs.npz")
+    mine, reference = _manifests_agree(out.with_suffix(".manifest.json"),
+                                       IO / "ref_embed_graphs.manifest.json", device="cuda")
+    assert mine["graph_spec_sha256"] == reference["graph_spec_sha256"]
+
+
+def test_cli_embed_on_the_gpu_against_the_reference_s_archives(tmp_path, capsys):
+    """``ginfinity embed --device cuda`` (cli.py:69-111) on the tables the reference embedded:
+    whole molecules (graphs built on the device) and windowed records with paired neighbours
+    and two context hops (context rows dropped at the head's store)."""
+    from ginfinity_amd import cli
+    gpu = ["--device", "cuda", "--allow-nondeterministic-cuda"]
+    out = tmp_path / "embed.npz"
+    assert cli.main(["embed", "--input", str(IO / "small.tsv"), "--output", str(out), *gpu]) == 0
+    _archives_agree(out, IO / "ref_embed.npz")
+    _manifests_agree(out.with_suffix(".manifest.json"), IO / "ref_embed.manifest.json",
+                     device="cuda")
+    windowed = tmp_path / "windowed.npz"     # the flags make_io_golden.py gave the reference
+    arguments = ["embed", "--input", str(IO / "windowed.tsv"), "--output", str(windowed), *gpu,
+                 "--keep-paired-neighbours", "--context-hops", "2"]
+    assert cli.main(arguments) == 0
+    capsys.readouterr()
+    _archives_agree(windowed, IO / "ref_windowed_embed.npz")

@@ -621,53 +621,81 @@ def test_fused_head_equals_standalone_head(gpu_encoder):
         engine.set_option(native.GFY_OPT_SEPARATE_HEAD, 0)
 
 
-def _plan_boundary_shard():
-    """One record whose 32-node tiles sit exactly on the limits of the layer kernel's tile
-    plans (csrc/gine_layer.inc): 8 in-edge slots per node, 96 far (out-of-tile) source rows
-    per tile; one over either limit must take the direct path and give the same numbers."""
+def _plan_boundary_shard(seed=11):
+    """One record whose 32-node tiles sit exactly on the limits of the layer kernels' tile plans
+    (csrc/gine_layer.inc): kLSlots = 8 in-edge slots per node and kLFar = 40 staged out-of-tile
+    ("far") source rows per tile, counted PER EDGE by the planner (tile_plan_from_edges: every
+    outside edge takes a stage row) and by the lazy CSR finish (csr_finish.inc: a tile writes
+    row_ptr / col / typ only if a row has more than 8 in-edges or the tile more than 40 outside
+    edges).  A tile over either limit takes the direct path, which READS those rows: the seam
+    the round-3 GPU aborts came from (a direct-path tile whose rows the lazy finish had not
+    written).  Returns (shard, {tile: "staged" | "direct"})."""
     from ginfinity_amd import GraphShard, GraphSpec
-    nodes = 32 * 6 + 7                      # ragged last tile
-    rng = np.random.default_rng(11)
+    nodes = 32 * 8 + 7                      # ragged last tile
+    rng = np.random.default_rng(seed)
     src, dst = [], []
 
-    def far_sources(tile, count):           # distinct nodes outside `tile`
+    def far_sources(tile, count, distinct=None):   # nodes outside `tile`
         pool = np.setdiff1d(np.arange(nodes), np.arange(32 * tile, 32 * tile + 32))
-        return rng.choice(pool, size=count, replace=False)
+        if distinct is None:
+            return rng.choice(pool, size=count, replace=False)
+        return rng.choice(rng.choice(pool, size=distinct, replace=False), size=count)
+
+    def spread(tile, sources):              # at most 8 in-edges per node, every source far
+        for k, s in enumerate(sources):
+            src.append(int(s)), dst.append(32 * tile + k % 32)
 
     for s in far_sources(0, 8):             # tile 0: node 3 has in-degree exactly 8 (staged)
-        src.append(s), dst.append(3)
-    for s in far_sources(1, 9):             # tile 1: node 40 has in-degree 9 (direct path)
-        src.append(s), dst.append(40)
-    for k, s in enumerate(far_sources(2, 96)):   # tile 2: exactly 96 far rows, 3 per node
-        src.append(s), dst.append(64 + k // 3)
-    for k, s in enumerate(far_sources(3, 97)):   # tile 3: 97 far rows (direct path)
-        src.append(s), dst.append(96 + k % 32)
-    for i in range(128, nodes):             # tiles 4-6: self loops, in-tile and backbone edges
+        src.append(int(s)), dst.append(3)
+    for s in far_sources(1, 9):             # tile 1: node 40 has in-degree 9 (hub: direct)
+        src.append(int(s)), dst.append(40)
+    spread(2, far_sources(2, 40))           # tile 2: exactly 40 outside edges (staged, lazy rows)
+    spread(3, far_sources(3, 41))           # tile 3: 41, right behind a lazy tile (direct)
+    spread(4, far_sources(4, 48, distinct=12))   # tile 4: 48 outside edges, 12 distinct rows (direct)
+    spread(5, far_sources(5, 36, distinct=6))    # tile 5: 36 outside edges, 6 distinct rows (staged)
+    for i in range(192, nodes):             # tiles 6-8: self loops, in-tile and backbone edges
         src.append(i), dst.append(i)
         if i + 1 < nodes:
             src.append(i + 1), dst.append(i)
             src.append(i), dst.append(i + 1)
-    for i in range(160, 192):               # the same far source for a whole tile, twice each
-        src += [5, 5]
+    for i in range(224, 256):               # tile 7: the same far source for a whole tile, twice
+        src += [5, 5]                       # each: 64 outside edges, one distinct row (direct)
         dst += [i, i]
     edge_index = np.array([src, dst], np.int32)
     order = rng.permutation(edge_index.shape[1])
     edge_index = np.ascontiguousarray(edge_index[:, order])
-    return GraphShard(
-        identifiers=("plans",), sequences=("A" * nodes,), structures=("." * nodes,),
+    roles = (rng.random(nodes) < 0.2).astype(np.uint8)
+    roles[0] = 0                            # a record keeps at least one core node
+    shard = GraphShard(
+        identifiers=(f"plans{seed}",), sequences=("A" * nodes,), structures=("." * nodes,),
         node_features=rng.standard_normal((nodes, 7)).astype(np.float32),
         edge_index=edge_index,
         edge_types=rng.integers(0, 10, edge_index.shape[1]).astype(np.uint8),
         node_ptr=np.array([0, nodes], np.int64),
         edge_ptr=np.array([0, edge_index.shape[1]], np.int64), spec=GraphSpec.bundled(),
-        residue_index=np.arange(nodes, dtype=np.int32),
-        node_roles=(rng.random(nodes) < 0.2).astype(np.uint8) * np.uint8(1))
+        residue_index=np.arange(nodes, dtype=np.int32), node_roles=roles)
+    return shard, {0: "staged", 1: "direct", 2: "staged", 3: "direct", 4: "direct", 5: "staged",
+                   6: "staged", 7: "direct", 8: "staged"}
+
+
+def _outside_edges_per_tile(shard):
+    """What planner and lazy finish count: in-edges whose source lies outside the tile."""
+    src, dst = shard.edge_index
+    outside = (src // 32) != (dst // 32)
+    return np.bincount(dst[outside] // 32, minlength=-(-shard.node_count // 32))
 
 
 def test_tile_plan_limits_against_oracle(gpu_encoder, oracle_weights):
     from oracle import gine_numpy as G
-    shard = _plan_boundary_shard()
-    shard.node_roles[0] = 0                 # a record keeps at least one core node
+    shard, paths = _plan_boundary_shard()
+    # the generator really sits on the limits it claims (else this test pins nothing)
+    outside = _outside_edges_per_tile(shard)
+    degree = np.bincount(shard.edge_index[1], minlength=shard.node_count)
+    assert outside[2] == 40 and outside[3] == 41 and outside[4] == 48 and outside[5] == 36
+    assert degree[3] == 8 and degree[40] == 9 and degree.max() == 9
+    for tile, path in paths.items():
+        hub = degree[32 * tile:32 * tile + 32].max() > 8
+        assert (path == "direct") == (hub or outside[tile] > 40), tile
     got = np.concatenate(gpu_encoder.encode_graphs(shard))
     want = G.encode(oracle_weights, shard.node_features, shard.edge_index, shard.edge_types)
     core = shard.node_roles == 0
@@ -687,6 +715,43 @@ def test_tile_plan_limits_against_oracle(gpu_encoder, oracle_weights):
         # one-ulp accumulation-order flips only (they compound through the layers)
         assert float(np.mean(h != ref)) < (0.05 if stage == 1 else 0.45), stage
         assert _maxabs(h, ref) < 0.06, stage
+
+
+@pytest.mark.parametrize("kernel", [1, 3, 4])
+def test_lazy_csr_rows_and_direct_path_tiles_in_a_batch(gpu_encoder, oracle_weights, kernel):
+    """The seam of the round-3 aborts, pinned: in ``gfy_encode_coo`` /
+    ``gfy_encode_coo_batch`` the CSR rows are written only by tiles that can take the direct
+    path, and a direct-path tile reads them.  The boundary shard — tiles with exactly 40 and 41
+    outside edges, 48 outside edges from 12 distinct rows, 36 from 6, a direct tile right behind
+    a lazy one, a hub — alone, and as the SECOND and THIRD shard of a batch (global row and edge
+    numbering, tile_base / edge_base not zero), on every layer kernel, against the oracle."""
+    import torch
+    from ginfinity_amd import synthetic
+    from oracle import gine_numpy as G
+    engine = gpu_encoder._engine
+    first = synthetic.arbitrary_shard(3)
+    boundary, _paths = _plan_boundary_shard()
+    other, _ = _plan_boundary_shard(seed=12)
+
+    def device(shard):
+        core = shard.node_roles == 0
+        table = np.cumsum(core, dtype=np.int32) - np.int32(1)
+        table[~core] = -1
+        x, ei, et = _device_inputs(gpu_encoder, shard)
+        return x, ei, et, torch.from_numpy(table).to(engine.device), int(core.sum())
+
+    try:
+        engine.set_option(native.GFY_OPT_LAYER_KERNEL, kernel)
+        alone = engine.encode_coo_batch([device(boundary)])[0].cpu().numpy()
+        batch = engine.encode_coo_batch([device(first), device(boundary), device(other)])
+        torch.cuda.synchronize()
+    finally:
+        engine.set_option(native.GFY_OPT_LAYER_KERNEL, -1)
+    for shard, got in ((boundary, alone), (boundary, batch[1].cpu().numpy()),
+                       (other, batch[2].cpu().numpy())):
+        want = G.encode(oracle_weights, shard.node_features, shard.edge_index, shard.edge_types)
+        assert _maxabs(got, want[shard.node_roles == 0]) <= F16_TOL
+    assert alone.tobytes() == batch[1].cpu().numpy().tobytes()
 
 
 def test_normalise_is_the_float64_quotient_rounded_once(gpu_encoder):

@@ -71,8 +71,28 @@ def main() -> None:
             from_file = min(from_file, time.perf_counter() - a)
             load_only = min(load_only, b - a)
         assert all(x.tobytes() == y.tobytes() for x, y in zip(outputs, outputs_file))
+    # device-resident leg (Ginfinity.stage_shards + encode_staged: what parallel.encode_owned_shards
+    # and bench.py --workload cross-shard run): inputs in HBM, embeddings left there; the
+    # micro-batches in groups of MICROBATCH_GROUP per launch sequence vs one by one
+    import torch
+    from ginfinity_amd import api
+    staged, _counts = encoder.stage_shards(shard)
+    device_leg = {}
+    for group in (api.MICROBATCH_GROUP, 1):
+        api.MICROBATCH_GROUP, keep = group, api.MICROBATCH_GROUP
+        block = encoder.encode_staged(staged)
+        torch.cuda.synchronize()
+        took = 1e9
+        for _ in range(5):
+            a = time.perf_counter()
+            encoder.encode_staged(staged, out=block)
+            torch.cuda.synchronize()
+            took = min(took, time.perf_counter() - a)
+        api.MICROBATCH_GROUP = keep
+        device_leg[f"group_of_{group}"] = {"seconds": took, "nodes_per_s": nodes / took}
     print(json.dumps({
         "workload": "encode_graphs(rouskin shard) numpy->numpy, fp16, default limits",
+        "encode_staged_device_resident": device_leg,
         "records": shard.record_count, "nodes": nodes, "edges": shard.edge_count,
         "read_table_s": t1 - t0, "build_shard_s": t2 - t1, "encode_graphs_s": best,
         "encode_many_s_device_built_graphs": many, "nodes_per_s_encode_many": nodes / many,
