@@ -22,6 +22,7 @@
 
 namespace gfy {
 #include "csr_finish.inc"
+#include "csr_count.inc"
 namespace {
 
 constexpr int kScanBlock = 256;
@@ -31,56 +32,16 @@ constexpr int kDirectScanTiles = 64;   // up to here every scan block sums its o
 
 constexpr int kCountEdgesPerBlock = kCsrCountEdgesPerBlock;   // gfy_common.h
 
-// kTileSums: also leave the number of edges per 32 destination rows (what the scan-free finish
-// sums).  One global atomic per edge would double the kernel (300 k more atomics: 6.5 -> 12 us,
-// and 86 us when the 32 edges of a backbone run hit one address from one wave): the block
-// counts its edges per tile in LDS first and adds the non-zero bins.
 template <bool kTileSums>
 __global__ __launch_bounds__(256) void k_csr_count(
     const ShardTable shards, int32_t* __restrict__ count, int2* __restrict__ table,
     int32_t* __restrict__ overflow, int32_t* __restrict__ overflow_count,
-    int32_t* __restrict__ tile_sum, int bins) {
-  // one bin per tile of THIS BLOCK'S shard (dynamic: 7.5 KB at 60,000 nodes — next to the 152 KB
-  // of a resident layer workgroup of another stream a static 16 KB would not fit on the CU)
+    int32_t* __restrict__ tile_sum, int bins, int total_blocks) {
   extern __shared__ int s_bins[];
-  const int shard = shards.shard_of_count_block(blockIdx.x);       // block-uniform
-  const int n = shards.nodes[shard], e_count = shards.edges[shard];
-  const int first_row = shards.tile_base[shard] * kCsrTileRows;
-  const int32_t* __restrict__ src = shards.edge_index[shard];
-  const int32_t* __restrict__ dst = src + e_count;
-  const uint8_t* __restrict__ types = shards.edge_types[shard];
-  if constexpr (kTileSums) {
-    for (int i = threadIdx.x; i < bins; i += 256) s_bins[i] = 0;
-    __syncthreads();
-  }
-  const int64_t first =
-      (int64_t)(blockIdx.x - shards.count_block_base[shard]) * kCountEdgesPerBlock;
-#pragma unroll
-  for (int k = 0; k < kCountEdgesPerBlock / 256; ++k) {
-    const int64_t e = first + k * 256 + threadIdx.x;
-    if (e >= e_count) continue;
-    const int32_t d = dst[e];
-    if ((uint32_t)d >= (uint32_t)n) continue;   // not an edge of this shard: not in any row
-    const int row = first_row + d;               // global numbering from here on
-    const int id = shards.edge_base[shard] + (int)e;
-    // the edge's source (global row) and type travel with its id: the finish stage then needs
-    // no second, scattered visit to the edge arrays (both are streamed here anyway)
-    const uint32_t from = (uint32_t)src[e];
-    const uint32_t packed = (from < (uint32_t)n ? (uint32_t)first_row + from : kCsrNoSource) |
-                            ((uint32_t)types[e] << 24);
-    const int slot = atomicAdd(&count[row], 1);
-    if (slot < kCsrSlots) table[(size_t)row * kCsrSlots + slot] = make_int2(id, (int)packed);
-    else overflow[atomicAdd(overflow_count, 1)] = id;
-    if constexpr (kTileSums) atomicAdd(&s_bins[d / kCsrTileRows], 1);
-  }
-  if constexpr (kTileSums) {
-    __syncthreads();
-    const int tiles = (n + kCsrTileRows - 1) / kCsrTileRows;
-    for (int i = threadIdx.x; i < tiles; i += 256) {
-      const int edges = s_bins[i];
-      if (edges) atomicAdd(&tile_sum[shards.tile_base[shard] + i], edges);
-    }
-  }
+  const int block = xcd_range_block((int)gridDim.x);
+  if (block >= total_blocks) return;                                // block-uniform
+  csr_count_block<kTileSums>(shards, count, table, overflow, overflow_count, tile_sum, bins,
+                             block, s_bins);
 }
 
 // block-wide exclusive scan of kScanTile ints held kScanItems per thread
@@ -304,11 +265,11 @@ int launch_csr_count_scan(const CsrScratch& w, int32_t* sums, const ShardTable& 
   const int blocks = shards.count_block_base[shards.shards];
   if (blocks > 0 && scan_free) {
     const int bins = (int)finish_tiles(largest_shard_nodes(shards));
-    k_csr_count<true><<<blocks, 256, (size_t)bins * sizeof(int), s>>>(
-        shards, w.count, w.table, w.overflow, w.overflow_count, w.tile_sum, bins);
+    k_csr_count<true><<<(blocks + 7) & ~7, 256, (size_t)bins * sizeof(int), s>>>(
+        shards, w.count, w.table, w.overflow, w.overflow_count, w.tile_sum, bins, blocks);
   } else if (blocks > 0) {
-    k_csr_count<false><<<blocks, 256, 0, s>>>(shards, w.count, w.table, w.overflow,
-                                              w.overflow_count, nullptr, 0);
+    k_csr_count<false><<<(blocks + 7) & ~7, 256, 0, s>>>(shards, w.count, w.table, w.overflow,
+                                                         w.overflow_count, nullptr, 0, blocks);
   }
   if (!scan_free) {
     const int tiles = (int)((n + kScanTile - 1) / kScanTile);

@@ -690,6 +690,10 @@ int launch_encode_coo_f16(const gfy_encoder* enc, const ShardTable& shards, int 
   GFY_REQUIRE(ws_bytes >= w.bytes, GFY_ERR_WORKSPACE,
               "gfy_encode_coo: workspace %zu < required %zu", ws_bytes, w.bytes);
   const bool scan_free = csr_scan_free(largest_shard_nodes(shards));
+  // (Counting blocks and the input Linear in ONE launch — two independent jobs — were
+  // measured: 41-46 us for the pair at 240,000 nodes against 16-22 + 17 us apart; the launch
+  // holds more blocks than the chip, so the Linear's blocks only start when counting blocks
+  // retire, and nothing overlaps.  profiles/README.md, round 4.)
   if (const int rc = launch_csr_count_scan(w.scratch, w.scan_sums, shards, scan_free, w.row_ptr,
                                            shards.total_rows(), s))
     return rc;
