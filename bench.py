@@ -187,10 +187,14 @@ def measured_traffic(kernel: str, nodes_per_launch: int):
             if summary.get("kernel_source_sha16") != kernel_source_sha16():
                 continue
             measured = summary["kernels"][kernel]["hbm_bytes_per_launch"]
-            return measured * nodes_per_launch / summary.get("nodes_per_launch", NODES)
+            return (measured * nodes_per_launch / summary.get("nodes_per_launch", NODES),
+                    f"profiles/{path.name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the "
+                    "same kernel source (hash-checked), taken in a separate run — not measured "
+                    "in this one")
         except (OSError, KeyError, ValueError):
             continue
-    return None
+    return None, ("none: no committed PMC pass matches the kernel source as it is now "
+                  "(tools/profile_round.sh + tools/pmc_summary.py)")
 
 
 def cpu_baseline(seconds: float) -> dict:
@@ -229,34 +233,43 @@ def distance_leg(rows: int, device) -> dict:
     """BASELINE configs[3]: nearest other row of every row, N x N never materialised."""
     from ginfinity_amd import distance, synthetic
     points = torch.from_numpy(synthetic.unit_rows(0, rows)).to(device)
-    distance.nearest(points[:4096], points[:4096], metric="l2")          # warm
-    torch.cuda.synchronize(device)
-    began, ended = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    began.record()
+    # One untimed search of the full size first (workspace, code, and the clock the part settles
+    # at under this load: a 4,096-row warm-up left the first full search to find it), then three
+    # timed ones, all reported; `seconds` is their median.  Round 3's single timed call read
+    # 0.2096 s on the driver's box and 0.1905 s on the builder's: one number cannot tell a box
+    # from a ramp.
     distance.nearest(points, metric="l2", exclude_self=True)
-    ended.record()
     torch.cuda.synchronize(device)
-    seconds = began.elapsed_time(ended) * 1e-3
+    timed = []
+    for _ in range(3):
+        began, ended = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        began.record()
+        distance.nearest(points, metric="l2", exclude_self=True)
+        ended.record()
+        torch.cuda.synchronize(device)
+        timed.append(began.elapsed_time(ended) * 1e-3)
+    seconds = sorted(timed)[1]
     tflops = 2.0 * rows * rows * 128 / seconds / 1e12
     return {"workload": f"all-pairs L2 nearest over {rows} x 128 fp16 unit rows "
                         "(BASELINE configs[3]); parity unpinned: the reference has no "
                         "implementation of this step",
-            "seconds": seconds, "pairs_per_s": rows * rows / seconds,
+            "seconds": seconds, "seconds_all": timed, "pairs_per_s": rows * rows / seconds,
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS,
                          "kernel": "k_pairwise"}}
 
 
 def cross_shard(args, rank: int, local_rank: int, world: int, distributed: bool, *,
-                device=None, encode_block=None, search=None, make_shard=None) -> dict | None:
+                device=None, encoder=None, search=None, make_shard=None) -> dict | None:
     """BASELINE configs[4] at a size that fits the run: every rank encodes its shards (no
     collective), the fp16 blocks are exchanged chunk by chunk (all_gather_into_tensor: RCCL
     over xGMI) while the chunks already there are searched, every rank keeps the nearest
     other row of ITS rows over all ranks' rows.  Parity unpinned.
 
-    ``device`` / ``encode_block`` / ``search`` / ``make_shard`` replace the GPU pieces (tests:
-    the driver logic — shard ownership, fences, MAX-reductions, offsets, the result line — runs
-    under gloo on CPU tensors with the oracle as the search)."""
+    ``device`` / ``encoder`` / ``search`` / ``make_shard`` replace the GPU pieces (tests: the
+    driver logic — shard ownership, staging, the grouped encode step, fences, MAX-reductions,
+    offsets, the result line — runs under gloo on CPU tensors with the oracle as the search;
+    ``encoder`` then is any object with ``stage_shards`` and ``encode_staged``)."""
     import torch.distributed as dist
     from ginfinity_amd import parallel, synthetic
     on_gpu = device is None
@@ -284,30 +297,24 @@ def cross_shard(args, rank: int, local_rank: int, world: int, distributed: bool,
     # Encode leg: this rank's shards, their micro-batches in groups of four per launch sequence
     # (Ginfinity.encode_staged = gfy_encode_coo_batch).  The shards are staged on the device
     # first and that upload is timed by itself: `encode` is the hot path with its inputs
-    # resident in HBM, `stage` the PCIe-bound feeding of it.
-    stage_s = 0.0
+    # resident in HBM, `stage` the PCIe-bound feeding of it.  A rank without
+    # shards walks the same fences with an empty block.
+    fence()
+    t0 = time.perf_counter()
+    staged, _counts = encoder.stage_shards([shards[s] for s in owned]) if owned else ([], [])
     if on_gpu:
-        fence()
-        t0 = time.perf_counter()
-        staged, _counts = encoder.stage_shards([shards[s] for s in owned]) if owned else ([], [])
         torch.cuda.synchronize(device)
-        stage_s = longest(time.perf_counter() - t0)
-        block = (encoder.encode_staged(staged) if staged else     # warm: workspace, result block
-                 torch.empty((0, 128), dtype=torch.float16, device=device))
-        if not staged:
-            encoder.encode_staged(encoder.stage_shards(make_shard(0))[0])
-        fence()
-        t0 = time.perf_counter()
-        if staged:
-            encoder.encode_staged(staged, out=block)
+    stage_s = longest(time.perf_counter() - t0)
+    block = (encoder.encode_staged(staged) if staged else      # warm: workspace, result block
+             torch.empty((0, 128), dtype=torch.float16, device=device))
+    if not staged:
+        encoder.encode_staged(encoder.stage_shards([make_shard(0)])[0])
+    fence()
+    t0 = time.perf_counter()
+    if staged:
+        encoder.encode_staged(staged, out=block)
+    if on_gpu:
         torch.cuda.synchronize(device)
-    else:       # tests: the driver around CPU stand-ins, one block per shard
-        encode_block(next(iter(shards.values())) if shards else make_shard(0))
-        fence()
-        t0 = time.perf_counter()
-        blocks = [encode_block(shards[s]) for s in owned]
-        block = (torch.cat(blocks) if blocks else
-                 torch.empty((0, 128), dtype=torch.float16, device=device))
     encode_s = longest(time.perf_counter() - t0)
     fence()
     t1 = time.perf_counter()
@@ -531,6 +538,7 @@ def main() -> None:
         plain = plain_layers(mean)
         one_round = full * NODES <= 256 * 8 * 32        # a CU gets at most one round of tiles
         kernel_name = "k_gine_layer_f16" if one_round else "k_gine_layer_w"
+        traffic, traffic_source = measured_traffic(kernel_name, full * NODES)
         roofline = {
             "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "kernel": kernel_name, "shards_per_launch": full,
@@ -543,7 +551,7 @@ def main() -> None:
                      "`isolated` is the kernel by itself, `pipeline_frac` the whole step"
                      if lanes > 1 else "one batch at a time: the span is the kernel by itself"),
             **layer_roofline(timed_ms),
-            "traffic": measured_traffic(kernel_name, full * NODES),
+            "traffic": traffic, "traffic_source": traffic_source,
             "isolated": {"configuration": "one batch at a time, one HIP event pair around the "
                                           "plain layer launches",
                          **layer_roofline(sum(plain) / len(plain))},

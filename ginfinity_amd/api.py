@@ -29,6 +29,7 @@ from __future__ import annotations
 from concurrent.futures import ThreadPoolExecutor
 import collections
 import queue
+import threading
 
 import json
 from pathlib import Path
@@ -140,6 +141,7 @@ def _settle(jobs) -> None:
 #: default mode only: results alive beyond this many page-locked bytes go to pageable memory
 PINNED_RESULT_LIMIT = 4 << 30
 _pinned_alive = [0]                     # bytes of page-locked result blocks not yet dropped
+_pinned_lock = threading.Lock()         # (finalizers run on whatever thread drops a block)
 
 
 def _pinned_block(shape, dtype: torch.dtype) -> torch.Tensor:
@@ -148,13 +150,15 @@ def _pinned_block(shape, dtype: torch.dtype) -> torch.Tensor:
     import weakref
     block = torch.empty(shape, dtype=dtype, pin_memory=True)
     size = block.numel() * block.element_size()
-    _pinned_alive[0] += size
+    with _pinned_lock:
+        _pinned_alive[0] += size
     weakref.finalize(block, _pinned_released, size)
     return block
 
 
 def _pinned_released(size: int) -> None:
-    _pinned_alive[0] -= size
+    with _pinned_lock:
+        _pinned_alive[0] -= size
 
 
 class _ParameterView:
@@ -232,7 +236,7 @@ class _DirectDownloader:
     stream, no host memcpy, no worker thread.  A copy is ENQUEUED only once the kernels that
     produce its rows have finished: a copy enqueued behind a still-pending cross-stream
     dependency was, on most boxes, served at a quarter of the rate (15.4 MB in 1.23 instead of
-    0.31 ms, one to four such copies per call; tools/api_probe3.py).  The launching thread
+    0.31 ms, one to four such copies per call; profiles/README.md, "D2H").  The launching thread
     therefore keeps the copies of unfinished micro-batches in a list and enqueues those whose
     event has happened whenever it passes by (``submit``, ``result``); a helper thread doing
     the same cost the packers and the launcher 1 ms of a call."""
@@ -354,7 +358,7 @@ class _Uploader:
         kernel).  The caller then says with ``hold`` which event ends those reads.  Used with
         page-locked results: an H2D copy per micro-batch can land on the copy engine that is
         busy bringing the embeddings back, and the kernels then wait 0.3 ms per micro-batch for
-        4 MB of input (tools/api_probe5.py: 7.3-7.7 ms per call instead of 6.2-6.6)."""
+        4 MB of input (profiles/README.md, "D2H": 7.3-7.7 ms per call instead of 6.2-6.6)."""
         slot, arrays, offsets, total = packed
         staging = self._staging[slot]
         if mapped:
@@ -714,7 +718,7 @@ class Ginfinity:
         row ranges of it.  Per-micro-batch output tensors came from torch's caching allocator
         with ``record_stream`` on the copy stream, so their reuse waited for events and a call
         could run into ``hipMalloc`` — device-wide, and 15 MB D2H copies next to it took 1.2 ms
-        instead of 0.3 (tools/api_probe3.py).  Safe to reuse call after call: a call returns
+        instead of 0.3 (profiles/README.md, "D2H").  Safe to reuse call after call: a call returns
         only when its last copy has landed (one encoder = serialized inference)."""
         width = self.embedding_dimension
         need = rows * width * torch.empty((), dtype=torch_dtype).element_size()

@@ -294,6 +294,10 @@ int launch_build_csr(const int32_t* edge_index, const uint8_t* edge_types,
               (long long)n, (long long)e);
   const ShardTable shards = single_shard(nullptr, edge_index, edge_types, n, e, nullptr, nullptr);
   const int64_t rows = shards.total_rows();   // n rounded up to whole 32-row tiles
+  // the counting kernel's table keeps an edge's source row in 24 bits (0xFFFFFF = none)
+  GFY_REQUIRE(rows < kCsrMaxRows, GFY_ERR_UNSUPPORTED,
+              "gfy_build_csr: at most 16,777,215 (padded) nodes per call (got %lld); split the "
+              "graph at record boundaries", (long long)rows);
   int32_t* sums = nullptr;
   size_t need = 0;
   const CsrScratch w = carve_csr(ws, rows, e, &sums, &need);

@@ -728,8 +728,8 @@ static int batch_table(const gfy_shard* shards, int count, const char* who, Shar
     tiles += (one.n_nodes + 31) / 32;
     edges += one.n_edges;
     blocks += (one.n_edges + kCsrCountEdgesPerBlock - 1) / kCsrCountEdgesPerBlock;
-    GFY_REQUIRE(tiles * 32 <= ((int64_t)1 << 24) && edges < INT32_MAX, GFY_ERR_UNSUPPORTED,
-                "%s: a batch holds at most 16,777,216 (padded) nodes and 2^31 - 1 edges", who);
+    GFY_REQUIRE(tiles * 32 < kCsrMaxRows && edges < INT32_MAX, GFY_ERR_UNSUPPORTED,
+                "%s: a batch holds at most 16,777,215 (padded) nodes and 2^31 - 1 edges", who);
   }
   t.tile_base[count] = (int)tiles;
   t.edge_base[count] = (int)edges;

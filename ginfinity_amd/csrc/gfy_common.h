@@ -228,6 +228,7 @@ constexpr int kCsrCountEdgesPerBlock = GFY_COUNT_EDGES_PER_BLOCK;
 constexpr int kCsrLocalScanTiles = 4096;   // up to here the finish stage derives row_ptr itself
 constexpr int kCsrStageFarRows = 40;   // out-of-tile rows a gather stage holds (= kLFar, gine_layer.inc)
 constexpr uint32_t kCsrNoSource = 0xFFFFFFu;   // table entry: the edge's source is outside its shard
+constexpr int64_t kCsrMaxRows = 0xFFFFFF;      // ... so a COO call addresses rows 0 .. 0xFFFFFE (strictly fewer than 2^24)
 struct CsrScratch {
   int32_t* count;              // [n + 1]   in-degree counters          (zero between calls)
   int32_t* overflow_count;     // [2]       list length, finish ticket  (zero between calls)

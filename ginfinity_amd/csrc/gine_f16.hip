@@ -686,6 +686,11 @@ size_t encode_coo_f16_workspace_bytes(int64_t rows, int64_t e) {
 
 int launch_encode_coo_f16(const gfy_encoder* enc, const ShardTable& shards, int out_dtype,
                           int normalise, void* ws, size_t ws_bytes, hipStream_t s) {
+  // before anything is launched (an error return must leave the workspace's counters zero): the
+  // counting kernel's table keeps an edge's source row in 24 bits, 0xFFFFFF = none
+  GFY_REQUIRE(shards.total_rows() < kCsrMaxRows, GFY_ERR_UNSUPPORTED,
+              "gfy_encode_coo: at most 16,777,215 (padded) nodes per call (got %lld); split "
+              "micro-batches / batches at record boundaries", (long long)shards.total_rows());
   const CooWorkspace w = carve_coo(ws, shards.total_rows(), shards.total_edges());
   GFY_REQUIRE(ws_bytes >= w.bytes, GFY_ERR_WORKSPACE,
               "gfy_encode_coo: workspace %zu < required %zu", ws_bytes, w.bytes);

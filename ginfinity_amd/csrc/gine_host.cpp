@@ -284,9 +284,9 @@ int gfy_host_encoder_create(const void* weight_pack_host, size_t bytes, int mode
 
 void gfy_host_encoder_destroy(gfy_host_encoder* encoder) { delete encoder; }
 
-int gfy_host_encode(const gfy_host_encoder* enc, const float* x, const int32_t* edge_index,
-                    const uint8_t* edge_types, int64_t n, int64_t e, const int32_t* out_rows,
-                    void* out, int out_dtype, int normalise, int threads) {
+static int host_encode(const gfy_host_encoder* enc, const float* x, const int32_t* edge_index,
+                       const uint8_t* edge_types, int64_t n, int64_t e, const int32_t* out_rows,
+                       void* out, int out_dtype, int normalise, int threads) {
   gfy::clear_error();
   if (!enc || !x || !out || n <= 0 || n >= INT32_MAX || e < 0 || e >= INT32_MAX ||
       (e > 0 && (!edge_index || !edge_types))) {
@@ -443,6 +443,28 @@ int gfy_host_encode(const gfy_host_encoder* enc, const float* x, const int32_t* 
     }
   });
   return GFY_OK;
+}
+
+// Nothing may unwind through the C ABI into the caller's interpreter: the buffers are
+// std::vectors of ~1 KB per node and the node blocks run on std::threads (bad_alloc,
+// system_error) — reported as a status, like every other failure.
+int gfy_host_encode(const gfy_host_encoder* enc, const float* x, const int32_t* edge_index,
+                    const uint8_t* edge_types, int64_t n, int64_t e, const int32_t* out_rows,
+                    void* out, int out_dtype, int normalise, int threads) {
+  try {
+    return host_encode(enc, x, edge_index, edge_types, n, e, out_rows, out, out_dtype, normalise,
+                       threads);
+  } catch (const std::bad_alloc&) {
+    gfy::set_error("gfy_host_encode: out of host memory for n=%lld e=%lld", (long long)n,
+                   (long long)e);
+    return GFY_ERR_WORKSPACE;
+  } catch (const std::exception& failure) {
+    gfy::set_error("gfy_host_encode: %s", failure.what());
+    return GFY_ERR_INVALID;
+  } catch (...) {
+    gfy::set_error("gfy_host_encode: unknown failure");
+    return GFY_ERR_INVALID;
+  }
 }
 
 }   // extern "C"

@@ -118,6 +118,11 @@ int gfy_build_graphs(const uint8_t* bases, const uint8_t* marks,
  *   row_ptr     int32 [N+1]    out
  *   col         int32 [E]      out: source node of each in-edge
  *   typ         uint8 [E]      out: edge type of each in-edge                */
+/* Limit of the COO entry points (gfy_build_csr, gfy_encode_coo, gfy_encode_coo_batch): the node
+ * count of a call, rounded up to whole 32-row tiles (a batch: the sum over its shards), must be
+ * below 16,777,215 — GFY_ERR_UNSUPPORTED otherwise, before anything is launched.  (The counting
+ * kernel keeps an edge's source row in 24 bits.)  gfy_encode with a caller-built CSR takes up to
+ * 16,777,216 nodes.  The reference's micro-batches hold 60,000 (api.py:147-148). */
 size_t gfy_csr_workspace_bytes(int64_t n_nodes, int64_t n_edges);
 int gfy_build_csr(const int32_t* edge_index, const uint8_t* edge_types,
                   int64_t n_nodes, int64_t n_edges, int32_t* row_ptr,

@@ -592,6 +592,22 @@ def test_abi_rejects_oversized_and_undersized_requests(gpu_encoder):
                             (1 << 24) + 1, 0, None, out.data_ptr(), native.GFY_F16, 1,
                             tiny.data_ptr(), 1 << 40, None)
     assert status == native.GFY_ERR_UNSUPPORTED
+    # the COO entry points keep an edge's source row in 24 bits (0xFFFFFF = none): a call over
+    # 2^24 - 32 padded rows or more is refused BEFORE anything is launched — nothing writes to
+    # the workspace, whose counters therefore stay zero (include/gfy.h)
+    ei = torch.zeros((2, 1), dtype=torch.int32, device=engine.device)
+    et = torch.zeros(1, dtype=torch.uint8, device=engine.device)
+    guard = torch.zeros(64, dtype=torch.uint8, device=engine.device)
+    for nodes in ((1 << 24) - 32, 1 << 24):
+        status = lib.gfy_encode_coo(engine._handle, x.data_ptr(), ei.data_ptr(), et.data_ptr(),
+                                    nodes, 1, None, out.data_ptr(), native.GFY_F16, 1,
+                                    guard.data_ptr(), 1 << 40, None)
+        assert status == native.GFY_ERR_UNSUPPORTED and b"16,777,215" in lib.gfy_last_error()
+        status = lib.gfy_build_csr(ei.data_ptr(), et.data_ptr(), nodes, 1, rp.data_ptr(),
+                                   rp.data_ptr(), et.data_ptr(), guard.data_ptr(), 1 << 40, None)
+        assert status == native.GFY_ERR_UNSUPPORTED
+    torch.cuda.synchronize()
+    assert not guard.any()
 
 
 def test_fused_head_equals_standalone_head(gpu_encoder):

@@ -158,6 +158,39 @@ def test_cross_shard_nearest_world_size_one_needs_no_process_group():
 
 # ---- bench.py --workload cross-shard: the DRIVER logic under gloo, GPU pieces stubbed ----------
 
+class _StandInEncoder:
+    """``Ginfinity.stage_shards`` / ``encode_staged`` on CPU tensors: a shard is its own rows, a
+    staged micro-batch is two of them at most (so shards split into ragged pieces), "encoding"
+    returns the rows — issued group by group with the product's own grouping (``api._groups``),
+    the group sizes kept for the test."""
+
+    def __init__(self) -> None:
+        self.groups: list[list[int]] = []
+
+    def stage_shards(self, shards, **_limits):
+        staged, counts = [], []
+        for shard in shards:
+            counts.append((int(shard.shape[0]),))
+            staged += [(shard[a:a + 2], None, None, None, int(shard[a:a + 2].shape[0]))
+                       for a in range(0, int(shard.shape[0]), 2)]
+        return staged, counts
+
+    def encode_staged(self, staged, *, out=None):
+        from ginfinity_amd import api
+        rows = sum(kept for *_arrays, kept in staged)
+        block = torch.empty((rows, 128), dtype=torch.float16) if out is None else out
+        assert tuple(block.shape) == (rows, 128)
+        first, sizes = 0, []
+        for group in api._groups(len(staged)):
+            sizes.append(len(group))
+            for index in group:
+                piece, *_rest, kept = staged[index]
+                block[first:first + kept] = piece
+                first += kept
+        self.groups.append(sizes)
+        return block
+
+
 def _bench_cross_shard_worker(rank: int, size: int, port: int, shards: int, queue) -> None:
     import argparse
     import sys
@@ -172,20 +205,15 @@ def _bench_cross_shard_worker(rank: int, size: int, port: int, shards: int, queu
         args = argparse.Namespace(shards=shards, chunk_rows=5)
         # shard s = 4 + s rows, every row recognisably its shard's; "encoding" returns them
         make_shard = lambda s: _rows(100 + s, 4 + s)
+        encoder = _StandInEncoder()
         line = bench.cross_shard(args, rank, rank, size, True, device=torch.device("cpu"),
-                                 encode_block=lambda shard: shard, search=_oracle_search,
-                                 make_shard=make_shard)
-        queue.put((rank, line))
+                                 encoder=encoder, search=_oracle_search, make_shard=make_shard)
+        queue.put((rank, line, encoder.groups))
     finally:
         dist.destroy_process_group()
 
 
-def test_bench_cross_shard_driver_logic_world_size_two():
-    """bench.py's cross-shard workload with the encoder and the matrix-core search replaced by
-    CPU stand-ins: shard s goes to rank s mod W, rank 0 prints ONE line whose totals and rank
-    offsets describe all ranks' rows, and the sample it reports is the true nearest other row."""
-    from oracle import gine_numpy as G
-    size, shards = 2, 5
+def _run_cross_shard_driver(size: int, shards: int):
     context = mp.get_context("spawn")
     queue = context.Queue()
     port = _free_port()
@@ -193,20 +221,51 @@ def test_bench_cross_shard_driver_logic_world_size_two():
              for r in range(size)]
     for p in procs:
         p.start()
-    results = dict(queue.get(timeout=240) for _ in procs)
+    results = {rank: (line, groups) for rank, line, groups in
+               (queue.get(timeout=240) for _ in procs)}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert results[1] is None and results[0] is not None           # one line, from rank 0
-    line = results[0]
+    return results
+
+
+def test_bench_cross_shard_driver_logic_world_size_two():
+    """bench.py's cross-shard workload with the encoder and the matrix-core search replaced by
+    CPU stand-ins: shard s goes to rank s mod W, every rank stages its shards and encodes them in
+    groups of four micro-batches (the last group ragged), rank 0 prints ONE line whose totals
+    and rank offsets describe all ranks' rows, and the sample it reports is the true nearest
+    other row."""
+    from oracle import gine_numpy as G
+    size, shards = 2, 5
+    results = _run_cross_shard_driver(size, shards)
+    assert results[1][0] is None and results[0][0] is not None      # one line, from rank 0
+    line = results[0][0]
     per_rank = [sum(4 + s for s in range(shards) if s % size == r) for r in range(size)]
     assert line["config"]["rows_total"] == sum(per_rank)
     assert line["config"]["rank_offsets"] == [0, per_rank[0], per_rank[0] + per_rank[1]]
     assert line["n_gpus"] == size and line["config"]["rccl_ranks"] == size
     assert line["unit"] == "pairs/s" and line["value"] > 0
+    assert line["encode"]["seconds"] > 0 and line["stage"]["seconds"] > 0
+    # rank 0: shards 0, 2, 4 = 4 + 6 + 8 rows = 2 + 3 + 4 staged pieces of two rows -> groups of
+    # 4, 4, 1 (warm-up call, then the timed one); rank 1: shards 1, 3 = 3 + 4 pieces -> 4, 3
+    assert results[0][1] == [[4, 4, 1], [4, 4, 1]]
+    assert results[1][1] == [[4, 3], [4, 3]]
     everything = np.concatenate(
         [_rows(100 + s, 4 + s).numpy() for r in range(size) for s in range(shards) if s % size == r])
     full = G.pairwise_cosine(everything, everything)
     np.fill_diagonal(full, -np.inf)
     assert line["sample"][1] == int(full[0].argmax())
     assert abs(line["sample"][0] - full[0].max()) < 1e-6
+
+
+def test_bench_cross_shard_driver_with_a_rank_that_owns_nothing():
+    """Three ranks, two shards: rank 2 has no shard — it stages nothing, warms on a shard it does
+    not keep, contributes zero rows to the exchange and still walks every fence and reduction."""
+    size, shards = 3, 2
+    results = _run_cross_shard_driver(size, shards)
+    line = results[0][0]
+    assert results[1][0] is None and results[2][0] is None
+    assert line["config"]["rows_total"] == 4 + 5
+    assert line["config"]["rank_offsets"] == [0, 4, 9, 9]
+    assert results[2][1] == [[2]]            # the warm-up on make_shard(0) only (4 rows: 2 pieces)
+    assert results[0][1] == [[2], [2]] and results[1][1] == [[3], [3]]

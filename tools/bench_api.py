@@ -15,7 +15,64 @@ from ginfinity_amd import (Ginfinity, GraphBuilder, load_graph_shard, read_rna_t
                            save_graph_shard)
 
 
+def d2h_probe() -> None:
+    """``--d2h-probe``: what the copy engine does with the 15 result copies of config 2 by
+    themselves — 15 chunks of one device block into one page-locked host block on one copy
+    stream, idle, beside compute, and beside 240 MB of 4-MB uploads; then the block as ONE copy.
+    (Round 3's one-off probes, folded in here: profiles/README.md, "D2H".)"""
+    import torch
+    dev = torch.device("cuda:0")
+    rows, width, chunks = 897588, 128, 15
+    per = rows // chunks
+    landing = torch.empty((rows, width), dtype=torch.float16, pin_memory=True)
+    blocks = [torch.randn((per, width), device=dev).half() for _ in range(chunks)]
+    stream, up_stream = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    busy = torch.randn((4096, 4096), device=dev)
+    up_src = [torch.empty(4 << 20, dtype=torch.uint8, pin_memory=True) for _ in range(15)]
+    up_dst = [torch.empty(4 << 20, dtype=torch.uint8, device=dev) for _ in range(15)]
+    report = {}
+    for label, compute_ms, uploads in (("idle", 0.0, False), ("compute_3ms", 3.0, False),
+                                       ("uploads", 0.0, True), ("uploads_compute_3ms", 3.0, True)):
+        runs = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            marks, t0 = [], time.perf_counter()
+            if uploads:
+                with torch.cuda.stream(up_stream):
+                    for _ in range(4):
+                        for a, b in zip(up_src, up_dst):
+                            b.copy_(a, non_blocking=True)
+            with torch.cuda.stream(stream):
+                for i, block in enumerate(blocks):
+                    a = torch.cuda.Event(enable_timing=True)
+                    a.record(stream)
+                    landing[i * per:(i + 1) * per].copy_(block, non_blocking=True)
+                    b = torch.cuda.Event(enable_timing=True)
+                    b.record(stream)
+                    marks.append((a, b))
+            until = time.perf_counter() + compute_ms * 1e-3
+            while time.perf_counter() < until:
+                torch.mm(busy, busy)
+            stream.synchronize()
+            total = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            runs.append({"total_ms": total * 1e3, "gbytes_per_s": rows * 256 / total / 1e9,
+                         "per_copy_ms": [round(a.elapsed_time(b), 3) for a, b in marks]})
+        report[label] = runs
+    one = torch.empty((rows, width), dtype=torch.float16, device=dev)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    landing.copy_(one, non_blocking=True)
+    torch.cuda.synchronize()
+    t = time.perf_counter() - t
+    report["one_copy"] = {"ms": t * 1e3, "gbytes_per_s": rows * 256 / t / 1e9}
+    print(json.dumps({"workload": "15 x 15.4 MB device -> page-locked host, one copy stream",
+                      **report}))
+
+
 def main() -> None:
+    if "--d2h-probe" in sys.argv[1:]:
+        return d2h_probe()
     t0 = time.perf_counter()
     records = read_rna_table(ROOT / "tests" / "golden" / "rouskin_sample_6k.tsv")
     t1 = time.perf_counter()

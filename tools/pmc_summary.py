@@ -24,14 +24,32 @@ def short(name: str) -> str:
     base = m.group(1)
     if base == "k_gine_layer_f16" and re.search(r"k_gine_layer_f16ILb[01]ELb1E", name):
         base = "k_gine_layer_f16<+head>"          # <kResidual, kHead>
+    if base in ("k_gine_layer_q", "k_gine_layer_w") and re.search(
+            base + r"ILb[01]ELb[01]ELb1E", name):
+        base += "<+head>"                         # <kResidual, kTap, kHead>
     return base
 
 
 def means(path: Path):
-    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    """Mean counter value per dispatch and kernel — over the dispatches of the kernel's LARGEST
+    grid only: a warm-up on a few rows (tools/bench_distance.py runs k_pairwise on 4,096 rows
+    before the 1M x 1M search) is another workload, and averaging it in halved every k_pairwise
+    counter of round 3's file."""
+    rows = collections.defaultdict(list)
     for row in csv.DictReader(open(path)):
-        agg[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
-    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}
+        rows[short(row["Kernel_Name"])].append(row)
+    out = {}
+    for kernel, dispatches in rows.items():
+        grid_of = lambda r: int(r.get("Grid_Size") or r.get("Grid_Size_X") or 0)
+        largest = max(grid_of(r) for r in dispatches)
+        kept = collections.defaultdict(list)
+        for r in dispatches:
+            if grid_of(r) == largest:
+                kept[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        out[kernel] = {c: sum(v) / len(v) for c, v in kept.items()}
+        out[kernel]["grid_size"] = largest
+        out[kernel]["dispatches_averaged"] = max(len(v) for v in kept.values())
+    return out
 
 
 traffic = collections.defaultdict(dict)
