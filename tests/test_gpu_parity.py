@@ -149,8 +149,10 @@ def test_hidden_stages_match_oracle(gpu_encoder, oracle_weights, rouskin_shard):
         want = trace[f"l{layer}.h"]
         mismatch = float(np.mean(got != want))
         print(f"layer {layer}: mismatch {mismatch:.4f} maxabs {_maxabs(got, want):.4f}")
-        assert mismatch < (0.03, 0.10, 0.25, 0.40)[layer], (layer, mismatch)
-        assert _maxabs(got, want) < 0.05, layer
+        # bounds = what round 4 measured (0.0061, 0.0507, 0.1846, 0.3665 of the elements one fp16
+        # ulp apart after layers 1..4; max |delta| 0.0039 / 0.0078 = one ulp of [4, 8)) + 25 %
+        assert mismatch < (0.008, 0.065, 0.23, 0.46)[layer], (layer, mismatch)
+        assert _maxabs(got, want) < 0.012, layer
     raw = engine.encode(x, csr, normalise=False).cpu().numpy()
     assert _maxabs(raw, trace["o"]) < 0.02
 
@@ -592,13 +594,14 @@ def test_abi_rejects_oversized_and_undersized_requests(gpu_encoder):
                             (1 << 24) + 1, 0, None, out.data_ptr(), native.GFY_F16, 1,
                             tiny.data_ptr(), 1 << 40, None)
     assert status == native.GFY_ERR_UNSUPPORTED
-    # the COO entry points keep an edge's source row in 24 bits (0xFFFFFF = none): a call over
-    # 2^24 - 32 padded rows or more is refused BEFORE anything is launched — nothing writes to
-    # the workspace, whose counters therefore stay zero (include/gfy.h)
+    # the COO entry points keep an edge's source row in 24 bits (0xFFFFFF = none): a call whose
+    # node count pads to 2^24 rows or more is refused BEFORE anything is launched — nothing
+    # writes to the workspace, whose counters therefore stay zero (include/gfy.h).  (Only refused
+    # sizes are tried: an accepted one would run on these ten-row arrays.)
     ei = torch.zeros((2, 1), dtype=torch.int32, device=engine.device)
     et = torch.zeros(1, dtype=torch.uint8, device=engine.device)
     guard = torch.zeros(64, dtype=torch.uint8, device=engine.device)
-    for nodes in ((1 << 24) - 32, 1 << 24):
+    for nodes in ((1 << 24) - 31, 1 << 24):
         status = lib.gfy_encode_coo(engine._handle, x.data_ptr(), ei.data_ptr(), et.data_ptr(),
                                     nodes, 1, None, out.data_ptr(), native.GFY_F16, 1,
                                     guard.data_ptr(), 1 << 40, None)
