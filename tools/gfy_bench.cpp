@@ -174,6 +174,7 @@ int main(int argc, char** argv) {
         for (int k = 1; k < 8; ++k) printf("  %-56s %8.0f\n", names[k], hs[k] / rounds);
         printf("  inside the products, waits at step 12 / 28 / 44 / 60, stage DMA issue: %.0f %.0f %.0f %.0f %.0f\n",
                hs[8] / rounds, hs[9] / rounds, hs[12] / rounds, hs[13] / rounds, (hs[14] - hs[13]) / rounds);
+        if (hs[15] > 0) printf("  diagnostic build: stage fill, last request -> landed: %.0f cycles\n", (hs[15] - hs[14]) / rounds);
         printf("  rounds per workgroup and launch %.2f, whole wave %.0f cycles per launch, %.0f per round\n",
                rounds / (128.0 * reps * 4), hs[10] / (128.0 * reps * 4), hs[10] / rounds);
       }
