@@ -163,7 +163,7 @@ int main(int argc, char** argv) {
     gfy_debug_stamps(&st[0][0], 0);
     double sum[16] = {0};
     for (int b = 0; b < 256; ++b) for (int k = 0; k < 16; ++k) sum[k] += (double)st[b][k];
-    if (layer_kernel == 4) {   // two 4-wave workgroups per CU: first and second residents apart
+    if (layer_kernel == 4 || (layer_kernel < 0 && N > 65536)) {   // windowed rounds (the default for several rounds of tiles): two 4-wave workgroups per CU, first and second residents apart
       const char* names[8] = {"prologue", "own rows + gather", "c0 | c1 + barrier", "products (4 barriers, c2, c3)",
                               "head launch: LN..head pipeline", "head launch: stage DMA issue", "LayerNorm + store (head: LN)", "wait for the next stage (head: normalise + store + wait)"};
       for (int half = 0; half < 2; ++half) {
