@@ -203,3 +203,24 @@ def test_torch_port_matches_reference_goldens(golden, checkpoint, rouskin_shard)
                      part16.edge_types, embedding_dtype=np.float32)
     assert np.abs(out32.astype(np.float64)
                   - g["out.m32.float32"].astype(np.float64)).max() <= F32_TOL
+
+
+def test_layernorm_inputs_are_far_from_the_cancellation_the_device_moments_guard(
+        golden, oracle_weights, rouskin_shard):
+    """The layer kernels take LayerNorm's variance as E[w^2] - mean^2 in fp32 (row sums on the
+    matrix cores, ginfinity_amd/csrc/gine_layer.inc: layer_norm_residual), which loses
+    log2(1 + mean^2 / var) bits, and fall back to centred values for a row beyond
+    mean^2 > 1023 var.  With the bundled weights the inputs stay four orders of magnitude inside
+    that: the reference's OWN recorded w tensors (stage.l*.w of rouskin64.npz, the input of
+    nn.LayerNorm, _model.py:69) and the oracle's trace on the arbitrary-graph shard."""
+    from ginfinity_amd import synthetic
+    g = golden("rouskin64.npz")
+    rows = [g[f"stage.l{layer}.w"].astype(np.float64) for layer in range(4)]
+    shard = synthetic.arbitrary_shard(0)
+    trace = {}
+    G.forward_f16(oracle_weights.half(), shard.node_features, shard.edge_index,
+                  shard.edge_types, trace)
+    rows += [trace[f"l{layer}.w"].astype(np.float64) for layer in range(4)]
+    for w in rows:
+        ratio = w.mean(axis=1) ** 2 / np.maximum(w.var(axis=1), 1e-30)
+        assert ratio.max() < 0.1, ratio.max()
