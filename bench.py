@@ -162,7 +162,8 @@ def launch_ranks(args: argparse.Namespace) -> "NoReturn":
 
 
 KERNEL_SOURCES = ("ginfinity_amd/csrc/gine_layer.inc", "ginfinity_amd/csrc/gine_layer_q.inc",
-                  "ginfinity_amd/csrc/gine_f16.hip", "ginfinity_amd/csrc/gfy_common.h")
+                  "ginfinity_amd/csrc/gine_layer_w.inc", "ginfinity_amd/csrc/gine_f16.hip",
+                  "ginfinity_amd/csrc/gfy_common.h")
 
 
 def kernel_source_sha16() -> str:
