@@ -317,6 +317,16 @@ def cross_shard(args, rank: int, local_rank: int, world: int, distributed: bool,
     if on_gpu:
         torch.cuda.synchronize(device)
     encode_s = longest(time.perf_counter() - t0)
+    # ... and the product path of a rank from HOST arrays: the uploads streamed under the
+    # compute (Ginfinity.encode_shards_device), what parallel.encode_owned_shards runs
+    streamed_s = None
+    if on_gpu and owned:
+        encoder.encode_shards_device([shards[s] for s in owned], out=block)      # warm
+        fence()
+        t0 = time.perf_counter()
+        encoder.encode_shards_device([shards[s] for s in owned], out=block)
+        torch.cuda.synchronize(device)
+        streamed_s = longest(time.perf_counter() - t0)
     fence()
     t1 = time.perf_counter()
     values, indices, offsets = parallel.cross_shard_nearest(
@@ -342,7 +352,13 @@ def cross_shard(args, rank: int, local_rank: int, world: int, distributed: bool,
                        "note": "inputs resident on the device, embeddings left there; the "
                                "micro-batches in groups of 4 per launch sequence"},
             "stage": {"seconds": stage_s,
-                      "note": "numpy shards -> device arrays of the owned shards (PCIe)"},
+                      "note": "numpy shards -> device arrays of the owned shards (PCIe, pageable, "
+                              "synchronous)"},
+            "encode_from_host_arrays": None if streamed_s is None else {
+                "seconds": streamed_s, "nodes_per_s": total / streamed_s,
+                "note": "numpy shards in, device block out: pinned staging ring, H2D of group "
+                        "g + 1 on a copy stream under the compute of group g "
+                        "(encode_shards_device)"},
             "exchange_and_search": {"seconds": search_s,
                                     "bytes_received_all_ranks": gathered_bytes,
                                     "tflops": 2.0 * total * total * 128 / search_s / 1e12},

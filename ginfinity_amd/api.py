@@ -146,6 +146,10 @@ def _settle(jobs) -> None:
                 pass
 
 
+#: packer threads of an encoder (numpy releases the GIL in the copies they make); one per
+#: staging slot of the uploader's ring at most
+_PACKERS = 8
+
 #: default mode only: results alive beyond this many page-locked bytes go to pageable memory
 PINNED_RESULT_LIMIT = 4 << 30
 _pinned_alive = [0]                     # bytes of page-locked result blocks not yet dropped
@@ -352,7 +356,10 @@ class _Uploader:
                     np.copyto(target, array)
                 else:
                     base, low, high = rebase
-                    np.subtract(array, base, out=target)
+                    if base:
+                        np.subtract(array, base, out=target)
+                    else:                      # a shard's first micro-batch: nothing to rebase
+                        np.copyto(target, array)
                     # one pass: as unsigned, a value below `low` wraps to ≥ 2^31 > high - low
                     if target.size and int(target.view(np.uint32).max()) >= high - low:
                         raise GraphValidationError("edge index outside shard node range")
@@ -408,6 +415,7 @@ class Ginfinity:
         self._device_block: torch.Tensor | None = None
         self._preparer: ThreadPoolExecutor | None = None
         self._uploader: _Uploader | None = None
+        self._copy_stream: "torch.cuda.Stream | None" = None
         self._metadata = checkpoint.metadata
         self._state = checkpoint.state
         self._config = checkpoint.config
@@ -531,7 +539,7 @@ class Ginfinity:
         # the positional columns (numpy sin / cos, GIL released) of later micro-batches are
         # computed on a second helper thread while this one uploads and launches
         if self._preparer is None:
-            self._preparer = ThreadPoolExecutor(max_workers=6,
+            self._preparer = ThreadPoolExecutor(max_workers=_PACKERS,
                                                 thread_name_prefix="ginfinity-prep")
         columns_of = [self._preparer.submit(text.positional, a, b) for a, b in bounds]
         assert MICROBATCH_GROUP <= self._uploader.slots   # a group's inputs live in the ring
@@ -641,7 +649,7 @@ class Ginfinity:
         if self._uploader is None:
             self._uploader = _Uploader(self._engine.device)
         if self._preparer is None:
-            self._preparer = ThreadPoolExecutor(max_workers=6,
+            self._preparer = ThreadPoolExecutor(max_workers=_PACKERS,
                                                 thread_name_prefix="ginfinity-prep")
         uploader = self._uploader
         core_counts = shard.core_count_array()
@@ -651,25 +659,7 @@ class Ginfinity:
         device_rows = self._device_rows(total_rows, torch_dtype)
 
         def prepare(slot: int, start: int, stop: int):
-            # the arrays of GraphShard.slice(start, stop) (graph.py:414-444: edge indices
-            # rebased to the first node of the range) without building — and re-validating —
-            # a GraphShard per micro-batch; the one check of GraphShard.__post_init__ that
-            # depends on the slice (graph.py:318-321 after the rebasing: an edge that leaves
-            # the micro-batch's node range, which the whole-shard range check cannot see) is
-            # made on the way into pinned memory and refused exactly as the reference refuses it
-            n0, n1 = int(shard.node_ptr[start]), int(shard.node_ptr[stop])
-            e0, e1 = int(shard.edge_ptr[start]), int(shard.edge_ptr[stop])
-            roles = shard.node_roles[n0:n1]
-            rows, kept = None, n1 - n0
-            if roles.any():                      # context nodes: dropped at the head's store
-                core = roles == 0
-                kept = int(np.count_nonzero(core))
-                rows = np.cumsum(core, dtype=np.int32) - np.int32(1)
-                rows[~core] = -1
-            packed = uploader.pack(slot, (
-                shard.node_features[n0:n1], (shard.edge_index[:, e0:e1], np.int32(n0), n0, n1),
-                shard.edge_types[e0:e1], rows))
-            return packed, kept
+            return self._pack_microbatch(uploader, slot, shard, start, stop)
 
         assert MICROBATCH_GROUP <= uploader.slots
         jobs: list = []
@@ -719,6 +709,30 @@ class Ginfinity:
             outputs.extend(self._splitter(counts, embedding_dtype, exact)(
                 host_block[row:row + kept]))
         return outputs
+
+    @staticmethod
+    def _pack_microbatch(uploader: "_Uploader", slot: int, shard: GraphShard, start: int,
+                         stop: int):
+        """Records [start, stop) of ``shard`` → pinned staging slot ``slot`` (packer threads):
+        the arrays of GraphShard.slice(start, stop) (graph.py:414-444: edge indices rebased to the
+        first node of the range) without building — and re-validating — a GraphShard per
+        micro-batch; the one check of GraphShard.__post_init__ that depends on the slice
+        (graph.py:318-321 after the rebasing: an edge that leaves the micro-batch's node range,
+        which the whole-shard range check cannot see) is made on the way into pinned memory and
+        refused exactly as the reference refuses it.  Returns ``(packed, kept core rows)``."""
+        n0, n1 = int(shard.node_ptr[start]), int(shard.node_ptr[stop])
+        e0, e1 = int(shard.edge_ptr[start]), int(shard.edge_ptr[stop])
+        roles = shard.node_roles[n0:n1]
+        rows, kept = None, n1 - n0
+        if roles.any():                      # context nodes: dropped at the head's store
+            core = roles == 0
+            kept = int(np.count_nonzero(core))
+            rows = np.cumsum(core, dtype=np.int32) - np.int32(1)
+            rows[~core] = -1
+        packed = uploader.pack(slot, (
+            shard.node_features[n0:n1], (shard.edge_index[:, e0:e1], np.int32(n0), n0, n1),
+            shard.edge_types[e0:e1], rows))
+        return packed, kept
 
     def _device_rows(self, rows: int, torch_dtype: torch.dtype) -> torch.Tensor:
         """[rows, 128] of ``torch_dtype`` on the device, a view of ONE block the encoder keeps
@@ -847,13 +861,74 @@ class Ginfinity:
         return block
 
     def encode_shards_device(self, shards: Sequence[GraphShard], *,
-                             max_batch_nodes: int = 60_000, max_batch_edges: int = 300_000
+                             max_batch_nodes: int = 60_000, max_batch_edges: int = 300_000,
+                             out: torch.Tensor | None = None
                              ) -> tuple[torch.Tensor, list[tuple[int, ...]]]:
         """Several shards → one device block of all their core rows (shard after shard) and
-        the per-record row counts of every shard: what a rank of ``parallel`` encodes."""
-        staged, counts = self.stage_shards(shards, max_batch_nodes=max_batch_nodes,
-                                           max_batch_edges=max_batch_edges)
-        return self.encode_staged(staged), counts
+        the per-record row counts of every shard: what a rank of ``parallel`` encodes.  The
+        host arrays STREAM in: packer threads slice and rebase the micro-batches into a ring of
+        page-locked staging slots, a copy stream brings group g + 1 up while group g (four
+        micro-batches, one ``gfy_encode_coo_batch``) is computed — the call is bound by the
+        larger of the two (4.4 MB per 60,000-node micro-batch against ≈ 75 µs of compute:
+        level), not by their sum.  Nothing returns to the host."""
+        if self._engine is None:
+            raise ValueError("device-resident encoding needs a GPU encoder (device='cuda')")
+        engine, device = self._engine, self._engine.device
+        plan: list[tuple[GraphShard, int, int]] = []
+        counts: list[tuple[int, ...]] = []
+        for shard in shards:
+            shard = self._checked_shard(shard, max_batch_nodes, max_batch_edges)
+            counts.append(shard.core_counts)
+            plan += [(shard, a, b) for a, b in microbatch_bounds(
+                shard.lengths, shard.edge_counts, max_batch_nodes, max_batch_edges)]
+        rows = sum(sum(per_record) for per_record in counts)
+        block = out
+        if block is None:
+            block = torch.empty((rows, self.embedding_dimension), dtype=torch.float16,
+                                device=device)
+        if (tuple(block.shape) != (rows, self.embedding_dimension)
+                or block.dtype != torch.float16 or not block.is_contiguous()):
+            raise ValueError("out must be a contiguous float16 [total core rows, 128] tensor")
+        if self._uploader is None:
+            self._uploader = _Uploader(device)
+        if self._preparer is None:
+            self._preparer = ThreadPoolExecutor(max_workers=_PACKERS,
+                                                thread_name_prefix="ginfinity-prep")
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=device)
+        uploader, copies = self._uploader, self._copy_stream
+        compute = torch.cuda.current_stream(device)
+        assert MICROBATCH_GROUP <= uploader.slots
+        jobs: list = []
+        first = 0
+        try:
+            for group in _groups(len(plan)):
+                # (a staging slot is free again once its H2D copy has left it: `pack` waits for
+                # the event `send` records on the copy stream)
+                while len(jobs) < len(plan) and len(jobs) < group.start + uploader.slots:
+                    shard, a, b = plan[len(jobs)]
+                    jobs.append(self._preparer.submit(self._pack_microbatch, uploader,
+                                                      uploader.reserve(), shard, a, b))
+                members = []
+                with torch.cuda.stream(copies):
+                    for index in group:
+                        packed, kept = jobs[index].result()
+                        views = uploader.send(packed)
+                        for view in views:
+                            if view is not None:     # allocated on the copy stream, read on
+                                view.record_stream(compute)   # the compute stream
+                        features, edge_index, edge_types, out_rows = views
+                        members.append((features, edge_index, edge_types, out_rows,
+                                        block[first:first + kept]))
+                        first += kept
+                    uploaded = torch.cuda.Event()
+                    uploaded.record(copies)
+                compute.wait_event(uploaded)
+                engine.encode_coo_group(members)
+        except BaseException:
+            _settle(jobs)
+            raise
+        return block, counts
 
     def encode_graphs_device(self, shard: GraphShard, *,
                              max_batch_nodes: int = 60_000,

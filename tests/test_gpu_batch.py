@@ -193,9 +193,14 @@ def test_records_and_device_blocks_take_the_grouped_path_too(gpu_encoder, rouski
     block, counts = gpu_encoder.encode_graphs_device(shard)
     assert engine.last_layer_kernel() == 4
     blocks, many = gpu_encoder.encode_shards_device([shard.slice(0, 700), shard.slice(700, 1500)])
+    # the resident-input form of the same thing (stage once, encode many times)
+    staged, staged_counts = gpu_encoder.stage_shards(shard)
+    resident = gpu_encoder.encode_staged(staged)
+    assert staged_counts == [shard.core_counts]
     monkeypatch.setattr(api, "MICROBATCH_GROUP", 1)
     single = np.concatenate(gpu_encoder.encode_many(records))
     assert grouped.tobytes() == single.tobytes()
     assert block.cpu().numpy().tobytes() == single.tobytes()
     assert blocks.cpu().numpy().tobytes() == single.tobytes()
+    assert resident.cpu().numpy().tobytes() == single.tobytes()
     assert counts == shard.core_counts and list(map(len, many)) == [700, 800]
