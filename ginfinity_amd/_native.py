@@ -11,6 +11,8 @@ from ctypes import (POINTER, Structure, c_char_p, c_int, c_int32, c_int64, c_siz
 from pathlib import Path
 
 LIBRARY_PATH = Path(__file__).resolve().parent / "csrc" / "libgfy.so"
+#: gine_host.cpp + gfy_base.cpp built with the host compiler: no HIP runtime behind it
+HOST_LIBRARY_PATH = Path(__file__).resolve().parent / "csrc" / "libgfy_host.so"
 
 GFY_OK = 0
 GFY_ERR_INVALID, GFY_ERR_UNSUPPORTED, GFY_ERR_HIP, GFY_ERR_WORKSPACE = 1, 2, 3, 4
@@ -85,6 +87,11 @@ SIGNATURES: dict[str, tuple] = {
 }
 
 
+#: what device="cpu" calls (a subset of SIGNATURES; libgfy.so exports them too)
+HOST_SYMBOLS = ("gfy_last_error", "gfy_abi_version", "gfy_weight_pack_bytes",
+                "gfy_host_encoder_create", "gfy_host_encoder_destroy", "gfy_host_encode")
+
+
 class NativeLibraryError(RuntimeError):
     """libgfy.so is missing, stale or reported a failure."""
 
@@ -123,12 +130,39 @@ def library() -> ctypes.CDLL:
     return lib
 
 
-def check(status: int, where: str) -> None:
+_host_library: ctypes.CDLL | None = None
+
+
+def host_library() -> ctypes.CDLL:
+    """libgfy_host.so: the host implementation by itself (no HIP runtime is loaded)."""
+    global _host_library
+    if _host_library is not None:
+        return _host_library
+    if not HOST_LIBRARY_PATH.is_file():
+        raise NativeLibraryError(
+            f"host library not built: {HOST_LIBRARY_PATH} is missing. Run "
+            "`python -m ginfinity_amd.build` (needs a C++17 host compiler only).")
+    try:
+        lib = ctypes.CDLL(str(HOST_LIBRARY_PATH))
+    except OSError as error:
+        raise NativeLibraryError(f"cannot load {HOST_LIBRARY_PATH}: {error}") from error
+    for name in HOST_SYMBOLS:
+        function = getattr(lib, name)
+        function.restype, function.argtypes = SIGNATURES[name]
+    if lib.gfy_abi_version() != ABI_VERSION:
+        raise NativeLibraryError(
+            f"{HOST_LIBRARY_PATH} has ABI {lib.gfy_abi_version()}, expected {ABI_VERSION}")
+    _host_library = lib
+    return lib
+
+
+def check(status: int, where: str, lib: ctypes.CDLL | None = None) -> None:
     """Turn a gfy status into the reference's exception conventions:
-    invalid arguments → ValueError, everything else → NativeLibraryError."""
+    invalid arguments → ValueError, everything else → NativeLibraryError.  ``lib``: the
+    library the call went to (its per-thread error string); libgfy.so by default."""
     if status == GFY_OK:
         return
-    message = library().gfy_last_error().decode("utf-8", "replace")
+    message = (lib or library()).gfy_last_error().decode("utf-8", "replace")
     text = f"{where}: {message or 'status ' + str(status)}"
     if status == GFY_ERR_INVALID:
         raise ValueError(text)

@@ -17,7 +17,11 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIBRARY = CSRC / "libgfy.so"
 SOURCES = ("gfy_api.hip", "graph_build.hip", "csr_build.hip", "gine_f16.hip",
-           "gine_f32.hip", "pairwise.hip", "gine_host.cpp")
+           "gine_f32.hip", "pairwise.hip", "gine_host.cpp", "gfy_base.cpp")
+# device="cpu" (the reference's default device) without any ROCm runtime on the box: the host
+# implementation and what it needs, built with the HOST compiler alone
+HOST_LIBRARY = CSRC / "libgfy_host.so"
+HOST_SOURCES = ("gine_host.cpp", "gfy_base.cpp")
 ARCH = "gfx950"
 # -ffp-contract=off: the rounding-point contract needs mul and add to round
 # separately unless the source says fma.
@@ -70,6 +74,12 @@ def build(force: bool = False, verbose: bool = False, stamps: bool = False) -> P
     if force or jobs or _stale(library, objects):
         run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}",
              "-o", str(library), *map(str, objects)])
+    if not stamps:
+        host_sources = [CSRC / name for name in HOST_SOURCES]
+        if force or _stale(HOST_LIBRARY, [*host_sources, *headers]):
+            run([os.environ.get("CXX", "g++"), "-O3", "-std=c++17", "-fPIC", "-shared",
+                 "-ffp-contract=off", "-fno-fast-math", "-pthread", "-Wall",
+                 "-o", str(HOST_LIBRARY), *map(str, host_sources)])
     return library
 
 

@@ -17,17 +17,9 @@
 
 namespace gfy {
 
-static thread_local std::string g_error;
-
-void set_error(const char* fmt, ...) {
-  char buf[512];
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(buf, sizeof buf, fmt, ap);
-  va_end(ap);
-  g_error = buf;
-}
-void clear_error() { g_error.clear(); }
+// (error channel, ABI version, weight-pack size: gfy_base.cpp, shared with libgfy_host.so)
+size_t pack_floats(uint32_t in_dim, uint32_t h, uint32_t layers, uint32_t edge_dim,
+                   uint32_t out_dim);
 
 void pack_b_fragments(const f16* w, int n_out, int k_in, f16* frag) {
   const int tiles = n_out / 32, ksteps = k_in / 16;
@@ -74,15 +66,7 @@ constexpr uint32_t kMagic = 0x31594647u;  // 'GFY1'
 struct PackHeader {
   uint32_t magic, version, in_dim, hidden, layers, edge_dim, out_dim, flags;
 };
-
-size_t pack_floats(uint32_t in_dim, uint32_t h, uint32_t layers,
-                   uint32_t edge_dim, uint32_t out_dim) {
-  const size_t per_layer = 1 + (size_t)h * edge_dim + h + (size_t)2 * h * h +
-                           2 * h + 4 * (size_t)(2 * h) + (size_t)h * 2 * h + h +
-                           2 * h;
-  return (size_t)h * in_dim + h + layers * per_layer + (size_t)h * h + h +
-         (size_t)out_dim * h + out_dim;
-}
+static_assert(sizeof(PackHeader) == 32, "gfy_weight_pack_bytes (gfy_base.cpp) counts 32 bytes");
 
 // bump allocator over a host staging image of the device blob
 struct Blob {
@@ -139,15 +123,6 @@ struct Reader {
 using namespace gfy;
 
 extern "C" {
-
-const char* gfy_last_error(void) { return g_error.c_str(); }
-int gfy_abi_version(void) { return GFY_ABI_VERSION; }
-
-size_t gfy_weight_pack_bytes(uint32_t in_dim, uint32_t hidden, uint32_t layers,
-                             uint32_t edge_dim, uint32_t out_dim) {
-  return sizeof(PackHeader) +
-         4 * pack_floats(in_dim, hidden, layers, edge_dim, out_dim);
-}
 
 int gfy_encoder_create(const void* weight_pack_host, size_t bytes,
                        int model_dtype, int device, gfy_encoder** out) {

@@ -1,5 +1,6 @@
 """``device="cpu"``: the reference's default device (src/ginfinity/api.py:64-76), served by
-the host implementation inside libgfy (csrc/gine_host.cpp): plain C++, the same
+the host implementation (csrc/gine_host.cpp, loaded as libgfy_host.so — built with the host
+compiler alone, so this device works on a box without any ROCm runtime): plain C++, the same
 rounding-point model as the kernels, threads over node blocks.  It exists so that the
 drop-in surface behaves like the reference on a box without a GPU (plumbing, small inputs,
 BASELINE configs[0]); it is not a fallback of the GPU path — an encoder loaded for
@@ -25,14 +26,14 @@ class HostEncoder:
 
     def __init__(self, weight_pack: bytes, *, full_precision: bool,
                  threads: int | None = None) -> None:
-        self._lib = native.library()
+        self._lib = native.host_library()
         self.full_precision = bool(full_precision)
         self.threads = int(threads) if threads else min(os.cpu_count() or 1, 16)
         handle = ctypes.c_void_p()
         native.check(self._lib.gfy_host_encoder_create(
             weight_pack, len(weight_pack),
             native.GFY_F32 if full_precision else native.GFY_F16, ctypes.byref(handle)),
-            "gfy_host_encoder_create")
+            "gfy_host_encoder_create", self._lib)
         self._handle = handle
 
     def close(self) -> None:
@@ -71,5 +72,6 @@ class HostEncoder:
         native.check(self._lib.gfy_host_encode(
             self._handle, pointer(features), pointer(edges) if count else None,
             pointer(types) if count else None, nodes, count, pointer(rows), pointer(out),
-            _GFY_OF_NUMPY[produced], 1 if normalise else 0, self.threads), "gfy_host_encode")
+            _GFY_OF_NUMPY[produced], 1 if normalise else 0, self.threads), "gfy_host_encode",
+            self._lib)
         return out if produced == wanted else out.astype(wanted)

@@ -163,3 +163,29 @@ def test_loaded_parameters_have_the_compute_dtype_and_hashing_stays_opt_in(tmp_p
     assert loaded.identifiers == ("a",)
     with pytest.raises(AssertionError, match="opt-in"):
         load_graph_shard(tensor_path, verify_checksum=True)
+
+
+def test_cpu_device_loads_only_the_host_library():
+    """device="cpu" (the reference's default, api.py:64-76) must work where no ROCm runtime
+    exists: it is served by libgfy_host.so — gine_host.cpp + gfy_base.cpp built with the host
+    compiler, no HIP dependency — and never maps libgfy.so.  In a fresh interpreter."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    script = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from ginfinity_amd import Ginfinity, RNA\n"
+        "out = Ginfinity.load().encode(RNA('example', 'ACGUACGU', '((....))'))\n"
+        "maps = open('/proc/self/maps').read()\n"
+        "assert out.shape == (8, 128), out.shape\n"
+        "assert 'libgfy_host.so' in maps\n"
+        "assert 'csrc/libgfy.so' not in maps, 'the CPU device mapped the HIP library'\n"
+        "print('ok')\n" % str(root))
+    done = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True,
+                          timeout=300)
+    assert done.returncode == 0 and done.stdout.strip() == "ok", done.stderr[-2000:]
+    needed = subprocess.run(["readelf", "-d", str(root / "ginfinity_amd" / "csrc" /
+                                                  "libgfy_host.so")],
+                            capture_output=True, text=True).stdout
+    assert "NEEDED" in needed and "hip" not in needed.lower() and "hsa" not in needed.lower()
