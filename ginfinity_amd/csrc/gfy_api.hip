@@ -383,6 +383,7 @@ int gfy_encoder_create(const void* weight_pack_host, size_t bytes,
       LayerF16& d = enc->f16.layer[l];
       const LayerOff& o = lo[l];
       d.scale = o.scale;
+      d.edge_types = ED;
       d.w01_image = H16(o.w01);
       d.image = base + o.image;
     }

@@ -88,6 +88,7 @@ inline int gemm_result_channel(int block, int half, int reg) {   // 32x32 C/D la
 
 struct LayerF16 {
   float scale;            // fp16 value R(1 + R(eps)) widened to fp32
+  int edge_types;         // edge_dim: rows of the edge table; an edge of another type is ignored
   const f16* w01_image;   // 128 KB: mlp.0.weight | mlp.4.weight fragments (pack_k_chained)
   const void* image;      // 7,680-byte LDS image: edge table R(W_edge[:,t] + b_edge) in stored
                           // order + the -inf row of idle slots; BatchNorm alpha = invstd*gamma,

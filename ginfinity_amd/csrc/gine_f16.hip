@@ -504,14 +504,15 @@ static int encode_f16_on(const gfy_encoder* enc, const ShardTable& shards, const
     else if (coo && coo->scan_free)   // + last CSR stage (row offsets included) + tile plans
       k_encode_setup_coo<false><<<layer_tiles + linear_blocks, 256, 0, s>>>(
           shards, enc->f16.w_in, enc->f16.b_in, ha, coo->scratch, coo->row_ptr, coo->col,
-          coo->typ, plans, layer_tiles);
+          coo->typ, plans, layer_tiles, enc->edge_dim);
     else if (coo)
       k_encode_setup_coo<true><<<layer_tiles + linear_blocks, 256, 0, s>>>(
           shards, enc->f16.w_in, enc->f16.b_in, ha, coo->scratch, coo->row_ptr, coo->col,
-          coo->typ, plans, layer_tiles);
+          coo->typ, plans, layer_tiles, enc->edge_dim);
     else            // + tile plans
       k_encode_setup<<<layer_tiles + linear_blocks, 256, 0, s>>>(
-          shards, enc->f16.w_in, enc->f16.b_in, ha, row_ptr, col, typ, plans, layer_tiles);
+          shards, enc->f16.w_in, enc->f16.b_in, ha, row_ptr, col, typ, plans, layer_tiles,
+          enc->edge_dim);
   }
   enc->mark(s, 1);
   const int stop = tap_stage >= 0 ? tap_stage : enc->layers;
@@ -737,7 +738,8 @@ int launch_debug_layer_f16(const gfy_encoder* enc, int layer, const void* hidden
   GFY_CHECK_HIP(hipMemsetAsync(ha, 0, h_buffer_bytes(rows), s));   // padding rows: zeros
   copy_rows((const f16*)hidden_in, ha, n * 8);                      // natural -> stored order
   k_encode_setup<<<layer_tiles, 256, 0, s>>>(shards, enc->f16.w_in, enc->f16.b_in, ha, row_ptr,
-                                             col, typ, plans, layer_tiles);   // plans only
+                                             col, typ, plans, layer_tiles,
+                                             enc->edge_dim);   // plans only
   const int tiles_per_xcd = (layer_tiles + 7) / 8;
   const int wanted = (tiles_per_xcd + kLWaves - 1) / kLWaves, per_xcd = enc->cus / 8;
   const int grid = 8 * (wanted < per_xcd ? wanted : per_xcd);

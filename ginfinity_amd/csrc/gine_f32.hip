@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void k_gather_f32(
     const float* __restrict__ h, const float* __restrict__ table /*[16][128]*/,
     float one_plus_eps, const int32_t* __restrict__ row_ptr,
     const int32_t* __restrict__ col, const uint8_t* __restrict__ typ,
-    float* __restrict__ z, int n) {
+    float* __restrict__ z, int n, int type_limit) {
   const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t node = item >> 5;
   const int c4 = (int)(item & 31);
@@ -78,6 +78,9 @@ __global__ __launch_bounds__(256) void k_gather_f32(
   for (int e = lo; e < hi; ++e) {
     const int s = col[e];
     const int t = typ[e];
+    // a source outside the shard or a type the model has no table row for cannot come from a
+    // validated shard (graph.py:318-323): the edge is ignored, as in the fp16 kernels
+    if ((uint32_t)s >= (uint32_t)n || (uint32_t)t >= (uint32_t)type_limit) continue;
     const f32x4 hv = *reinterpret_cast<const f32x4*>(h + (size_t)s * kHidden + c4 * 4);
     const f32x4 tv = *reinterpret_cast<const f32x4*>(table + t * kHidden + c4 * 4);
 #pragma unroll
@@ -275,7 +278,7 @@ int launch_encode_f32(const gfy_encoder* enc, const float* x,
     const LayerF32& p = m.layer[l];
     const int64_t items = n * 32;
     k_gather_f32<<<(int)((items + 255) / 256), 256, 0, s>>>(
-        h, p.table, p.one_plus_eps, row_ptr, col, typ, z, nn);
+        h, p.table, p.one_plus_eps, row_ptr, col, typ, z, nn, enc->edge_dim);
     DenseArgs a{};
     a.n = nn;
     a.in = z;

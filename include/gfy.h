@@ -135,6 +135,10 @@ int gfy_build_csr(const int32_t* edge_index, const uint8_t* edge_types,
  * LayerNorm, residual), 2-layer head.  Replaces api.py:237-252 and
  * _model.py:39-46,65-72.
  *   node_features float32 [N][in_dim]          (graph.py:302-305)
+ *   (edge values are the caller's to validate, as GraphShard does: graph.py:318-323.  The device
+ *   entry points never read outside the arrays for any VALUE in them: an edge whose source is
+ *   outside [0, N) or whose type is >= edge_dim is IGNORED — it contributes no message —; the
+ *   host entry point gfy_host_encode returns GFY_ERR_INVALID for such an edge)
  *   row_ptr/col/typ                            from gfy_build_csr
  *   out_rows      int32 [N] or NULL: output row of node i, -1 = drop the node
  *                 (context nodes of sliced graphs, api.py:253-260); NULL = i

@@ -947,3 +947,52 @@ def test_encoders_created_and_used_from_two_threads(rouskin_shard):
     assert not errors, errors
     np.testing.assert_array_equal(results[0][0], results[1][0])
     np.testing.assert_array_equal(results[0][1], results[1][1])
+
+
+@pytest.mark.parametrize("kernel", [1, 3, 4])
+def test_edges_of_unknown_type_or_source_are_ignored_not_trusted(gpu_encoder, gpu_encoder_fp32,
+                                                                 kernel):
+    """The reference refuses edge types >= edge_dim and sources outside the shard when the shard
+    is built (graph.py:318-323); a caller of the C ABI can pass anything.  The device paths
+    neither fault nor read another table row for such an edge: it contributes no message — the
+    result equals the same graph WITHOUT those edges — on staged tiles, on the direct path (a hub
+    row) and on every layer kernel (the windowed one keeps its plan-head slots in the edge
+    table's unused rows, which such a type would otherwise address), fp16 and fp32 model."""
+    from ginfinity_amd import synthetic
+    shard = synthetic.arbitrary_shard(5)
+    rng = np.random.default_rng(3)
+    edges = shard.edge_count
+    hub = np.array([np.arange(40, 52), np.full(12, 7)], np.int32)      # node 7: in-degree > 8
+    edge_index = np.concatenate([shard.edge_index, hub], axis=1)
+    edge_types = np.concatenate([shard.edge_types, rng.integers(0, 10, 12).astype(np.uint8)])
+    bad = rng.choice(edge_index.shape[1], size=60, replace=False)
+    poisoned_types = edge_types.copy()
+    poisoned_index = edge_index.copy()
+    poisoned_types[bad[:30]] = rng.integers(10, 256, 30).astype(np.uint8)   # types 10..255
+    poisoned_index[0, bad[30:]] = shard.node_count + rng.integers(0, 1 << 20, 30)   # sources
+    poisoned_index[0, bad[55:]] = -5
+    keep = np.ones(edge_index.shape[1], bool)
+    keep[bad] = False
+
+    def run(encoder, index, types):
+        engine = encoder._engine
+        dtype = torch.float32 if encoder.full_precision else torch.float16
+        x = torch.from_numpy(shard.node_features).to(engine.device)
+        ei = torch.from_numpy(np.ascontiguousarray(index)).to(engine.device)
+        et = torch.from_numpy(np.ascontiguousarray(types)).to(engine.device)
+        return engine.encode_coo_batch([(x, ei, et, None, None)] * 5, out_dtype=dtype)[4].cpu().numpy()
+
+    engine = gpu_encoder._engine
+    try:
+        engine.set_option(native.GFY_OPT_LAYER_KERNEL, kernel)
+        clean = run(gpu_encoder, edge_index[:, keep], edge_types[keep])
+        poisoned = run(gpu_encoder, poisoned_index, poisoned_types)
+    finally:
+        engine.set_option(native.GFY_OPT_LAYER_KERNEL, -1)
+    assert np.isfinite(poisoned.astype(np.float32)).all()
+    assert poisoned.tobytes() == clean.tobytes()
+    if kernel == 1:     # the fp32 model has one gather kernel
+        clean32 = run(gpu_encoder_fp32, edge_index[:, keep], edge_types[keep])
+        poisoned32 = run(gpu_encoder_fp32, poisoned_index, poisoned_types)
+        assert poisoned32.tobytes() == clean32.tobytes()
+    assert edges == shard.edge_count
