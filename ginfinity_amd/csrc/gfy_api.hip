@@ -260,8 +260,10 @@ int gfy_encoder_create(const void* weight_pack_host, size_t bytes,
             const float prod = mean * alpha;  // separate rounding (no fma)
             ia[at] = alpha;
             is[at] = b - prod;
-            ib0[at] = rh(b0[c]);
           }
+      // b0 and b1 are added on the matrix cores (gine_layer.inc, mlp_pipe_step): natural channel
+      // order — row lane % 32 of A-operand block b is channel 32 b + row
+      for (int c = 0; c < M; ++c) ib0[c] = rh(b0[c]);
       f16* ib1 = reinterpret_cast<f16*>(im + 4352 + 2048 + 512);
       f16* ig = ib1 + H;
       f16* ib = ig + H;
@@ -270,7 +272,7 @@ int gfy_encoder_create(const void* weight_pack_host, size_t bytes,
           for (int reg = 0; reg < 16; ++reg) {
             const int c = gemm_result_channel(blk, half, reg);
             const int at = (blk * 2 + half) * 16 + reg;
-            ib1[at] = rh(b1[c]);
+            ib1[c] = rh(b1[c]);
             ig[at] = rh(lg[c]);
             ib[at] = rh(lb[c]);
           }

@@ -92,8 +92,9 @@ struct LayerF16 {
   const f16* w01_image;   // 128 KB: mlp.0.weight | mlp.4.weight fragments (pack_k_chained)
   const void* image;      // 7,680-byte LDS image: edge table R(W_edge[:,t] + b_edge) in stored
                           // order + the -inf row of idle slots; BatchNorm alpha = invstd*gamma,
-                          // shift = beta - mean*alpha (fp32, from fp16-rounded buffers), b0, b1,
-                          // LayerNorm gamma, beta as [block][lane half][register] of an MFMA result
+                          // shift = beta - mean*alpha (fp32, from fp16-rounded buffers) and
+                          // LayerNorm gamma, beta as [block][lane half][register] of an MFMA
+                          // result; b0, b1 in natural channel order (added on the matrix cores)
 };
 
 struct HeadF16 {
