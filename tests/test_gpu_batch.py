@@ -101,6 +101,38 @@ def test_stand_alone_head_behind_persistent_rounds_gives_the_same_bytes(gpu_enco
         assert a.tobytes() == b.tobytes()
 
 
+def test_random_batches_give_the_same_bytes_on_every_layer_kernel(gpu_encoder):
+    """Twelve random batches (2-6 shards each: RNA-like records of 64 / 500 / 1,000 / 4,000
+    nodes, interchange shards with hubs, context nodes and all edge types — staged tiles,
+    direct-path tiles, ragged last rounds): the one-round kernel, the persistent rounds and
+    the two windowed workgroups per CU must agree bit for bit, shard by shard."""
+    engine = gpu_encoder._engine
+    rng = np.random.default_rng(4)
+    try:
+        for _ in range(12):
+            shards = []
+            for _ in range(int(rng.integers(2, 7))):
+                if rng.random() < 0.3:
+                    shards.append(synthetic.arbitrary_shard(
+                        int(rng.integers(0, 1000)), nodes=int(rng.integers(2000, 30000)),
+                        edges=int(rng.integers(5000, 120000)), records=4,
+                        hub_degree=int(rng.integers(1, 60))))
+                else:
+                    shards.append(synthetic.roofline_shard(
+                        int(rng.integers(0, 1000)), records=int(rng.integers(1, 16)),
+                        length=int(rng.choice([64, 500, 1000, 4000]))))
+            inputs = [_device(engine, shard) for shard in shards]
+            outs = {}
+            for kernel in (1, 3, 4):
+                engine.set_option(native.GFY_OPT_LAYER_KERNEL, kernel)
+                outs[kernel] = [o.cpu().numpy() for o in engine.encode_coo_batch(inputs)]
+            for kernel in (3, 4):
+                for a, b in zip(outs[1], outs[kernel]):
+                    assert a.tobytes() == b.tobytes()
+    finally:
+        engine.set_option(native.GFY_OPT_LAYER_KERNEL, -1)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_batch_other_output_dtypes_equal_single(gpu_encoder, mixed_shards, dtype):
     engine = gpu_encoder._engine
