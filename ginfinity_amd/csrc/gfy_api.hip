@@ -448,10 +448,11 @@ int gfy_encoder_set_option(gfy_encoder* enc, int option, int value) {
       enc->separate_head = value;
       return GFY_OK;
     case GFY_OPT_LAYER_KERNEL:
-      GFY_REQUIRE(value == -1 || value == 1 || value == 3 || value == 4, GFY_ERR_INVALID,
+      GFY_REQUIRE(value == -1 || value == 1 || value == 3 || value == 4 || value == 5,
+                  GFY_ERR_INVALID,
                   "gfy_encoder_set_option: GFY_OPT_LAYER_KERNEL must be -1 (by rounds), 1 (round-2 "
-                  "kernel), 3 (persistent rounds) or 4 (two windowed workgroups per CU), got %d",
-                  value);
+                  "kernel), 3 (persistent rounds), 4 (two windowed workgroups per CU) or 5 (three "
+                  "workgroups per CU), got %d", value);
       enc->layer_kernel = value;
       return GFY_OK;
     case GFY_OPT_STAGGER:

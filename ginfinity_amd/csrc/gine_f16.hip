@@ -396,8 +396,14 @@ __global__ __launch_bounds__(256) void k_copy_rows_f16(const f16* __restrict__ s
 #include "csr_finish.inc"
 #include "gine_layer.inc"
 #include "gine_layer_q.inc"
+#include "gine_block_pipe.inc"
 #include "gine_layer_w.inc"
+#include "gine_layer_x.inc"
 
+#ifdef GFY_PROBE_BUILD   // tools/mlp_probe.hip: the device code above, none of the launch code below
+}  // namespace
+}  // namespace gfy
+#else
 int persistent_grid(int num_tiles) {
   int g = num_tiles < 256 ? num_tiles : 256;
   g = (g + 7) & ~7;  // whole XCD rounds (TileWalk divides by 8)
@@ -460,6 +466,11 @@ int prepare_device_f16() {   // gfy_encoder_create, with the encoder's device cu
     GFY_OPT_IN((k_gine_layer_w<true, false, true>), kWLdsBytes);
     GFY_OPT_IN((k_gine_layer_w<false, false, true>), kWLdsBytes);
     GFY_OPT_IN((k_gine_layer_w<true, true, false>), kWLdsBytes);
+    GFY_OPT_IN((k_gine_layer_x<true, false, false>), kXLdsBytes);
+    GFY_OPT_IN((k_gine_layer_x<false, false, false>), kXLdsBytes);
+    GFY_OPT_IN((k_gine_layer_x<true, false, true>), kXLdsBytes);
+    GFY_OPT_IN((k_gine_layer_x<false, false, true>), kXLdsBytes);
+    GFY_OPT_IN((k_gine_layer_x<true, true, false>), kXLdsBytes);
 #undef GFY_OPT_IN
     return GFY_OK;
   });
@@ -534,14 +545,21 @@ static int encode_f16_on(const gfy_encoder* enc, const ShardTable& shards, const
   // ... and, where the edge table leaves its last rows free for the plan-head slots, as two
   // 4-wave workgroups per CU with the weights streamed through a window (gine_layer_w.inc)
   const bool window_ok = enc->edge_dim <= kWMaxEdgeTypes;
+  // ... or as three 4-wave workgroups per CU of <= 168 registers (gine_layer_x.inc)
+  const bool triple = window_ok && enc->layer_kernel == 5;
   const bool windowed =
-      window_ok && (enc->layer_kernel == 4 || (enc->layer_kernel < 0 && rounds > 1));
+      !triple && window_ok && (enc->layer_kernel == 4 || (enc->layer_kernel < 0 && rounds > 1));
   const bool persistent =
-      !windowed && (enc->layer_kernel >= 3 || (enc->layer_kernel < 0 && rounds > 1));
+      !triple && !windowed && (enc->layer_kernel >= 3 || (enc->layer_kernel < 0 && rounds > 1));
   const int w_wanted = (tiles_per_xcd + kWWaves - 1) / kWWaves, w_per_xcd = 2 * per_xcd;
   const int w_grid = 8 * (w_wanted < w_per_xcd ? w_wanted : w_per_xcd);
   const int w_rounds = (w_wanted + w_per_xcd - 1) / w_per_xcd;
-  enc->last_layer_kernel = windowed ? 4 : persistent ? 3 : 1;
+  const int x_wanted = (tiles_per_xcd + kXWaves - 1) / kXWaves, x_per_xcd = 3 * per_xcd;
+  const int x_grid = 8 * (x_wanted < x_per_xcd ? x_wanted : x_per_xcd);
+  const int x_rounds = (x_wanted + x_per_xcd - 1) / x_per_xcd;
+  const int x_stagger = enc->stagger >= 0 ? enc->stagger : x_rounds >= 2 ? 250 : 0;
+  const int x_priority = enc->priority >= 0 ? enc->priority : 0x24;   // residents 0, 1, 2 at levels 0, 1, 2
+  enc->last_layer_kernel = triple ? 5 : windowed ? 4 : persistent ? 3 : 1;
   const int w_stagger = enc->stagger >= 0 ? enc->stagger : w_rounds >= 3 ? 250 : 0;
   // the second workgroup of a CU multiplies at s_setprio 1 (gine_layer_w.inc)
   const int w_priority = enc->priority >= 0 ? enc->priority : 4;
@@ -577,7 +595,15 @@ static int encode_f16_on(const gfy_encoder* enc, const ShardTable& shards, const
       enc->f16.layer[l], ha, hb, csr_rows, csr_col, csr_typ, plans, csr_limit, layer_tiles,  \
       w_stagger, w_priority, spent, span, kTapNone, nullptr,         \
       HEAD ? head_out : no_out)
-    if (windowed && enc->residual && with_head) GFY_LAUNCH_WINDOW(true, true);
+#define GFY_LAUNCH_TRIPLE(RES, HEAD)                                                         \
+  k_gine_layer_x<RES, false, HEAD><<<x_grid, kXThreads, kXLdsBytes, s>>>(                    \
+      enc->f16.layer[l], ha, hb, csr_rows, csr_col, csr_typ, plans, csr_limit, layer_tiles,  \
+      x_stagger, x_priority, spent, span, kTapNone, nullptr, HEAD ? head_out : no_out)
+    if (triple && enc->residual && with_head) GFY_LAUNCH_TRIPLE(true, true);
+    else if (triple && enc->residual) GFY_LAUNCH_TRIPLE(true, false);
+    else if (triple && with_head) GFY_LAUNCH_TRIPLE(false, true);
+    else if (triple) GFY_LAUNCH_TRIPLE(false, false);
+    else if (windowed && enc->residual && with_head) GFY_LAUNCH_WINDOW(true, true);
     else if (windowed && enc->residual) GFY_LAUNCH_WINDOW(true, false);
     else if (windowed && with_head) GFY_LAUNCH_WINDOW(false, true);
     else if (windowed) GFY_LAUNCH_WINDOW(false, false);
@@ -592,6 +618,7 @@ static int encode_f16_on(const gfy_encoder* enc, const ShardTable& shards, const
 #undef GFY_LAUNCH_LAYER
 #undef GFY_LAUNCH_ROUNDS
 #undef GFY_LAUNCH_WINDOW
+#undef GFY_LAUNCH_TRIPLE
     f16* sw = ha;
     ha = hb;
     hb = sw;
@@ -609,7 +636,7 @@ static int encode_f16_on(const gfy_encoder* enc, const ShardTable& shards, const
     GFY_CHECK_HIP(hipGetLastError());
     return GFY_OK;
   }
-  if (out_dtype == GFY_F16 && (persistent || windowed)) {
+  if (out_dtype == GFY_F16 && (persistent || windowed || triple)) {
     k_head_d<<<p_grid, kLThreads, kLdsBytes, s>>>(enc->f16.head, ha, shards, layer_tiles,
                                                   normalise);
   } else {   // the tiled stand-alone head, shard by shard (f32 / f64 output, A/B runs)
@@ -740,12 +767,31 @@ int launch_debug_layer_f16(const gfy_encoder* enc, int layer, const void* hidden
   k_encode_setup<<<layer_tiles, 256, 0, s>>>(shards, enc->f16.w_in, enc->f16.b_in, ha, row_ptr,
                                              col, typ, plans, layer_tiles,
                                              enc->edge_dim);   // plans only
+  // the tap instantiation of the layer kernel the encoder is set to (GFY_OPT_LAYER_KERNEL 4 / 5:
+  // windowed / three workgroups per CU, where the edge table leaves room for their plan-head
+  // slots; anything else: persistent rounds, whose pipelines the one-round kernel shares)
   const int tiles_per_xcd = (layer_tiles + 7) / 8;
-  const int wanted = (tiles_per_xcd + kLWaves - 1) / kLWaves, per_xcd = enc->cus / 8;
-  const int grid = 8 * (wanted < per_xcd ? wanted : per_xcd);
-  k_gine_layer_q<true, true, false><<<grid, kLThreads, kQLdsBytes, s>>>(
-      enc->f16.layer[layer], ha, hb, row_ptr, col, typ, plans, (int)n, layer_tiles, 0, nullptr,
-      nullptr, tap, taps, HeadOut{});
+  const int per_xcd = enc->cus / 8;
+  const bool slots_ok = enc->edge_dim <= kWMaxEdgeTypes;
+  if (slots_ok && enc->layer_kernel == 5) {
+    const int wanted = (tiles_per_xcd + kXWaves - 1) / kXWaves;
+    const int grid = 8 * (wanted < 3 * per_xcd ? wanted : 3 * per_xcd);
+    k_gine_layer_x<true, true, false><<<grid, kXThreads, kXLdsBytes, s>>>(
+        enc->f16.layer[layer], ha, hb, row_ptr, col, typ, plans, (int)n, layer_tiles, 0, 0,
+        nullptr, nullptr, tap, taps, HeadOut{});
+  } else if (slots_ok && enc->layer_kernel == 4) {
+    const int wanted = (tiles_per_xcd + kWWaves - 1) / kWWaves;
+    const int grid = 8 * (wanted < 2 * per_xcd ? wanted : 2 * per_xcd);
+    k_gine_layer_w<true, true, false><<<grid, kWThreads, kWLdsBytes, s>>>(
+        enc->f16.layer[layer], ha, hb, row_ptr, col, typ, plans, (int)n, layer_tiles, 0, 0,
+        nullptr, nullptr, tap, taps, HeadOut{});
+  } else {
+    const int wanted = (tiles_per_xcd + kLWaves - 1) / kLWaves;
+    const int grid = 8 * (wanted < per_xcd ? wanted : per_xcd);
+    k_gine_layer_q<true, true, false><<<grid, kLThreads, kQLdsBytes, s>>>(
+        enc->f16.layer[layer], ha, hb, row_ptr, col, typ, plans, (int)n, layer_tiles, 0, nullptr,
+        nullptr, tap, taps, HeadOut{});
+  }
   if (tap == kTapNone) copy_rows(hb, (f16*)out, n * 8);
   else copy_rows(taps, (f16*)out, n * (tap == kTapV ? 16 : 8));   // stored -> natural order
   GFY_CHECK_HIP(hipGetLastError());
@@ -753,3 +799,4 @@ int launch_debug_layer_f16(const gfy_encoder* enc, int layer, const void* hidden
 }
 
 }  // namespace gfy
+#endif   // GFY_PROBE_BUILD

@@ -48,7 +48,7 @@ def _single(engine, shard, out_dtype=torch.float16):
     return engine.encode_coo(x, ei, et, out_rows=rows, n_out=kept, out_dtype=out_dtype).cpu().numpy()
 
 
-@pytest.mark.parametrize("kernel", [-1, 1, 3, 4])
+@pytest.mark.parametrize("kernel", [-1, 1, 3, 4, 5])
 def test_batch_is_bit_identical_to_single_shards(gpu_encoder, mixed_shards, kernel):
     engine = gpu_encoder._engine
     try:
@@ -81,7 +81,7 @@ def test_batch_of_synthetic_shards_matches_the_reference_rows(gpu_encoder, golde
         assert outs[seed].cpu().numpy().tobytes() == _single(engine, shards[seed]).tobytes()
 
 
-@pytest.mark.parametrize("kernel", [3, 4])
+@pytest.mark.parametrize("kernel", [3, 4, 5])
 def test_stand_alone_head_behind_persistent_rounds_gives_the_same_bytes(gpu_encoder, mixed_shards,
                                                                          kernel):
     """GFY_OPT_SEPARATE_HEAD: head + normalise as their own launch (k_head_d) behind the
@@ -104,8 +104,9 @@ def test_stand_alone_head_behind_persistent_rounds_gives_the_same_bytes(gpu_enco
 def test_random_batches_give_the_same_bytes_on_every_layer_kernel(gpu_encoder):
     """Twelve random batches (2-6 shards each: RNA-like records of 64 / 500 / 1,000 / 4,000
     nodes, interchange shards with hubs, context nodes and all edge types — staged tiles,
-    direct-path tiles, ragged last rounds): the one-round kernel, the persistent rounds and
-    the two windowed workgroups per CU must agree bit for bit, shard by shard."""
+    direct-path tiles, ragged last rounds): the one-round kernel, the persistent rounds, the
+    two windowed workgroups per CU and the three workgroups per CU of gine_layer_x.inc must agree
+    bit for bit, shard by shard."""
     engine = gpu_encoder._engine
     rng = np.random.default_rng(4)
     try:
@@ -123,10 +124,10 @@ def test_random_batches_give_the_same_bytes_on_every_layer_kernel(gpu_encoder):
                         length=int(rng.choice([64, 500, 1000, 4000]))))
             inputs = [_device(engine, shard) for shard in shards]
             outs = {}
-            for kernel in (1, 3, 4):
+            for kernel in (1, 3, 4, 5):
                 engine.set_option(native.GFY_OPT_LAYER_KERNEL, kernel)
                 outs[kernel] = [o.cpu().numpy() for o in engine.encode_coo_batch(inputs)]
-            for kernel in (3, 4):
+            for kernel in (3, 4, 5):
                 for a, b in zip(outs[1], outs[kernel]):
                     assert a.tobytes() == b.tobytes()
     finally:

@@ -736,7 +736,7 @@ def test_tile_plan_limits_against_oracle(gpu_encoder, oracle_weights):
         assert _maxabs(h, ref) < 0.06, stage
 
 
-@pytest.mark.parametrize("kernel", [1, 3, 4])
+@pytest.mark.parametrize("kernel", [1, 3, 4, 5])
 def test_lazy_csr_rows_and_direct_path_tiles_in_a_batch(gpu_encoder, oracle_weights, kernel):
     """The seam of the round-3 aborts, pinned: in ``gfy_encode_coo`` /
     ``gfy_encode_coo_batch`` the CSR rows are written only by tiles that can take the direct
@@ -949,7 +949,7 @@ def test_encoders_created_and_used_from_two_threads(rouskin_shard):
     np.testing.assert_array_equal(results[0][1], results[1][1])
 
 
-@pytest.mark.parametrize("kernel", [1, 3, 4])
+@pytest.mark.parametrize("kernel", [1, 3, 4, 5])
 def test_edges_of_unknown_type_or_source_are_ignored_not_trusted(gpu_encoder, gpu_encoder_fp32,
                                                                  kernel):
     """The reference refuses edge types >= edge_dim and sources outside the shard when the shard

@@ -163,7 +163,27 @@ int main(int argc, char** argv) {
     gfy_debug_stamps(&st[0][0], 0);
     double sum[16] = {0};
     for (int b = 0; b < 256; ++b) for (int k = 0; k < 16; ++k) sum[k] += (double)st[b][k];
-    if (layer_kernel == 4 || (layer_kernel < 0 && N > 65536)) {   // windowed rounds (the default for several rounds of tiles): two 4-wave workgroups per CU, first and second residents apart
+    if (layer_kernel == 5) {   // three 4-wave workgroups per CU: first, second and third residents apart
+      const char* names[9] = {"prologue", "gather, channels 0..63", "second stage fill (issue + wait)", "gather, channels 64..127",
+                              "c0 | c1 + barrier", "products (8 barriers, c2..c7)", "LayerNorm + store (head: LN)",
+                              "wait for the next stage (head: normalise + store + wait)", "head launch: head pipeline"};
+      for (int res = 0; res < 3; ++res) {
+        double hs[16] = {0};
+        for (int b = 64 * res; b < 64 * (res + 1); ++b) for (int k = 0; k < 16; ++k) hs[k] += (double)st[b][k];
+        const double rounds = hs[11] > 0 ? hs[11] : 1;
+        printf("three-workgroup layer kernel, resident %d of the CUs, shader cycles per round (wave 0):\n", res);
+        for (int k = 1; k < 9; ++k) printf("  %-56s %8.0f\n", names[k], hs[k] / rounds);
+        printf("  rounds per workgroup and launch %.2f, whole wave %.0f cycles per launch, %.0f per round\n",
+               rounds / (64.0 * reps * 4), hs[10] / (64.0 * reps * 4), hs[10] / rounds);
+      }
+      static unsigned long long real[512][2];
+      gfy_debug_real(&real[0][0]);
+      double life = 0; int used = 0;
+      for (int b = 0; b < 512; ++b)
+        if (real[b][1] > real[b][0]) life += (real[b][1] - real[b][0]) / 100.0, ++used;
+      if (used) printf("  last launch: workgroup lifetime %.1f us (mean of %d) -> %.2f GHz\n", life / used, used,
+                       sum[10] / (192.0 * reps * 4) / (life / used) / 1e3);
+    } else if (layer_kernel == 4 || (layer_kernel < 0 && N > 65536)) {   // windowed rounds (the default for several rounds of tiles): two 4-wave workgroups per CU, first and second residents apart
       const char* names[8] = {"prologue", "own rows + gather", "c0 | c1 + barrier", "products (4 barriers, c2, c3)",
                               "head launch: LN..head pipeline", "head launch: stage DMA issue", "LayerNorm + store (head: LN)", "wait for the next stage (head: normalise + store + wait)"};
       for (int half = 0; half < 2; ++half) {
