@@ -423,9 +423,14 @@ def main() -> None:
     # inputs resident in HBM before the timed region
     shards = [synthetic.roofline_shard(1000 * rank + i) for i in range(POOL)]
     assert all((s.node_count, s.edge_count) == (NODES, EDGES) for s in shards)
-    inputs = [(torch.from_numpy(s.node_features).to(device),
-               torch.from_numpy(s.edge_index).to(device),
-               torch.from_numpy(s.edge_types).to(device)) for s in shards]
+    # ... as Ginfinity.stage_shards puts them there: the record boundaries (graph.py:268-271) ride
+    # along, and the batch call turns COO into tile plans without global atomics
+    # (GFY_BENCH_NO_RECORDS=1: without them, for A/B runs against the counting kernel)
+    with_records = os.environ.get("GFY_BENCH_NO_RECORDS", "") in ("", "0")
+    inputs = [engine.upload_arrays(s.node_features, s.edge_index, s.edge_types, None,
+                                   node_ptr=s.node_ptr if with_records else None,
+                                   edge_ptr=s.edge_ptr if with_records else None)[:3]
+              for s in shards]
     outputs = [[torch.empty((NODES, 128), dtype=torch.float16, device=device)
                 for _ in range(batch)] for _ in range(lanes)]
     handles = [s.cuda_stream for s in streams]

@@ -24,13 +24,14 @@ GFY_OPT_STAGGER = 4
 GFY_OPT_PRIORITY = 6
 GFY_MAX_BATCH_SHARDS = 16
 GFY_TAP_H, GFY_TAP_Z, GFY_TAP_V, GFY_TAP_W, GFY_TAP_Y = 0, 1, 2, 3, 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 class GfyShard(Structure):
     """``gfy_shard`` of include/gfy.h: one shard of a batch (device pointers)."""
     _fields_ = [("node_features", c_void_p), ("edge_index", c_void_p),
                 ("edge_types", c_void_p), ("out_rows", c_void_p), ("out", c_void_p),
-                ("n_nodes", c_int64), ("n_edges", c_int64)]
+                ("n_nodes", c_int64), ("n_edges", c_int64),
+                ("node_ptr", c_void_p), ("edge_ptr", c_void_p), ("n_records", c_int64)]
 
 
 #: every symbol include/gfy.h declares: (restype, argtypes)
@@ -141,7 +142,8 @@ def host_library() -> ctypes.CDLL:
     if not HOST_LIBRARY_PATH.is_file():
         raise NativeLibraryError(
             f"host library not built: {HOST_LIBRARY_PATH} is missing. Run "
-            "`python -m ginfinity_amd.build` (needs a C++17 host compiler only).")
+            "`python -m ginfinity_amd.build --host-only` (a C++17 host compiler; no hipcc, no "
+            "ROCm runtime).")
     try:
         lib = ctypes.CDLL(str(HOST_LIBRARY_PATH))
     except OSError as error:

@@ -38,7 +38,7 @@ from typing import Sequence
 import numpy as np
 import torch
 
-from .engine import DeviceEncoder, device_output_dtype
+from .engine import DeviceEncoder, attach_records, device_output_dtype, records_pay
 from .host import HostEncoder
 from .graph import Graph, GraphBuilder, GraphShard, shard_text
 from .records import RNA
@@ -679,8 +679,10 @@ class Ginfinity:
                     jobs.append(self._preparer.submit(prepare, uploader.reserve(), a, b))
                 for index in group:
                     packed, kept = jobs[index].result()
-                    features, edge_index, edge_types, out_rows = uploader.send(packed,
-                                                                               mapped=direct)
+                    features, edge_index, edge_types, out_rows, node_ptr, edge_ptr = \
+                        uploader.send(packed, mapped=direct)
+                    if node_ptr is not None:
+                        attach_records(edge_index, node_ptr, edge_ptr)
                     members.append((packed, (features, edge_index, edge_types, out_rows,
                                              device_rows[first_row:first_row + kept])))
                     start, stop = bounds[index]
@@ -729,9 +731,14 @@ class Ginfinity:
             kept = int(np.count_nonzero(core))
             rows = np.cumsum(core, dtype=np.int32) - np.int32(1)
             rows[~core] = -1
+        # the record boundaries go up as they are (the kernels subtract the first entry): two
+        # arrays of records + 1 int64, and COO -> tile plans then needs no global atomics
+        node_ptr = edge_ptr = None
+        if records_pay(shard.node_ptr[start:stop + 1], shard.edge_ptr[start:stop + 1]):
+            node_ptr, edge_ptr = shard.node_ptr[start:stop + 1], shard.edge_ptr[start:stop + 1]
         packed = uploader.pack(slot, (
             shard.node_features[n0:n1], (shard.edge_index[:, e0:e1], np.int32(n0), n0, n1),
-            shard.edge_types[e0:e1], rows))
+            shard.edge_types[e0:e1], rows, node_ptr, edge_ptr))
         return packed, kept
 
     def _device_rows(self, rows: int, torch_dtype: torch.dtype) -> torch.Tensor:
@@ -830,7 +837,8 @@ class Ginfinity:
                                           max_batch_nodes, max_batch_edges):
                 piece = shard if (a, b) == (0, shard.record_count) else shard.slice(a, b)
                 staged.append(self._engine.upload_arrays(
-                    piece.node_features, piece.edge_index, piece.edge_types, piece.node_roles))
+                    piece.node_features, piece.edge_index, piece.edge_types, piece.node_roles,
+                    node_ptr=piece.node_ptr, edge_ptr=piece.edge_ptr))
         return staged, counts
 
     def encode_staged(self, staged: Sequence[tuple], *,
@@ -917,7 +925,9 @@ class Ginfinity:
                         for view in views:
                             if view is not None:     # allocated on the copy stream, read on
                                 view.record_stream(compute)   # the compute stream
-                        features, edge_index, edge_types, out_rows = views
+                        features, edge_index, edge_types, out_rows, node_ptr, edge_ptr = views
+                        if node_ptr is not None:
+                            attach_records(edge_index, node_ptr, edge_ptr)
                         members.append((features, edge_index, edge_types, out_rows,
                                         block[first:first + kept]))
                         first += kept

@@ -673,13 +673,14 @@ int gfy_encode_coo(gfy_encoder* enc, const float* x, const int32_t* edge_index,
   enc->last_stream = (hipStream_t)stream;
   if (enc->model_dtype == GFY_F16)
     return launch_encode_coo_f16(enc, single_shard(x, edge_index, edge_types, n, e, out_rows, out),
-                                 out_dtype, normalise, ws, ws_bytes, (hipStream_t)stream);
+                                 nullptr, out_dtype, normalise, ws, ws_bytes, (hipStream_t)stream);
   return encode_coo_f32(enc, x, edge_index, edge_types, n, e, out_rows, out, out_dtype, normalise,
                         ws, ws_bytes, (hipStream_t)stream);
 }
 
 // ---- a batch of shards in one sequence of launches ---------------------------------------
-static int batch_table(const gfy_shard* shards, int count, const char* who, ShardTable* table) {
+static int batch_table(const gfy_shard* shards, int count, const char* who, ShardTable* table,
+                       RecordTable* records = nullptr, bool* has_records = nullptr) {
   GFY_REQUIRE(shards && count >= 1 && count <= GFY_MAX_BATCH_SHARDS, GFY_ERR_INVALID,
               "%s: 1..%d shards per call (got %d)", who, GFY_MAX_BATCH_SHARDS, count);
   ShardTable t{};
@@ -714,6 +715,29 @@ static int batch_table(const gfy_shard* shards, int count, const char* who, Shar
   t.edge_base[count] = (int)edges;
   t.count_block_base[count] = (int)blocks;
   *table = t;
+  if (records && has_records) {   // record boundaries: all shards or none
+    RecordTable r{};
+    bool all = true;
+    int ranges = 0;
+    for (int s = 0; s < count; ++s) {
+      const gfy_shard& one = shards[s];
+      const bool given = one.node_ptr && one.edge_ptr && one.n_records > 0;
+      GFY_REQUIRE(given || (!one.node_ptr && !one.edge_ptr), GFY_ERR_INVALID,
+                  "%s: shard %d: node_ptr, edge_ptr and n_records go together", who, s);
+      GFY_REQUIRE(!given || one.n_records <= one.n_nodes, GFY_ERR_INVALID,
+                  "%s: shard %d: %lld records for %lld nodes", who, s, (long long)one.n_records,
+                  (long long)one.n_nodes);
+      all = all && given;
+      r.node_ptr[s] = one.node_ptr;
+      r.edge_ptr[s] = one.edge_ptr;
+      r.records[s] = (int)one.n_records;
+      r.range_base[s] = ranges;
+      ranges += (int)((one.n_nodes + kRecRows - 1) / kRecRows);
+    }
+    r.range_base[count] = ranges;
+    *records = r;
+    *has_records = all;
+  }
   return GFY_OK;
 }
 
@@ -747,14 +771,18 @@ int gfy_encode_coo_batch(gfy_encoder* enc, const gfy_shard* shards, int count, i
   GFY_REQUIRE(out_dtype == GFY_F16 || out_dtype == GFY_F32 || out_dtype == GFY_F64,
               GFY_ERR_INVALID, "gfy_encode_coo_batch: unsupported out_dtype %d", out_dtype);
   ShardTable t;
-  if (const int rc = batch_table(shards, count, "gfy_encode_coo_batch", &t)) return rc;
+  RecordTable records;
+  bool has_records = false;
+  if (const int rc = batch_table(shards, count, "gfy_encode_coo_batch", &t, &records, &has_records))
+    return rc;
   const size_t need = gfy_encode_coo_batch_workspace_bytes(enc, shards, count);
   GFY_REQUIRE(ws_bytes >= need, GFY_ERR_WORKSPACE,
               "gfy_encode_coo_batch: workspace %zu < required %zu", ws_bytes, need);
   if (const int rc = check_current_device(enc, "gfy_encode_coo_batch")) return rc;
   enc->last_stream = (hipStream_t)stream;
   if (enc->model_dtype == GFY_F16)
-    return launch_encode_coo_f16(enc, t, out_dtype, normalise, ws, ws_bytes, (hipStream_t)stream);
+    return launch_encode_coo_f16(enc, t, has_records ? &records : nullptr, out_dtype, normalise, ws,
+                                 ws_bytes, (hipStream_t)stream);
   for (int s = 0; s < count; ++s)
     if (const int rc = encode_coo_f32(enc, shards[s].node_features, shards[s].edge_index,
                                       shards[s].edge_types, shards[s].n_nodes, shards[s].n_edges,

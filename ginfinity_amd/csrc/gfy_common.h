@@ -218,6 +218,24 @@ struct ShardTable {
   }
 };
 
+// Optional record boundaries of a batch's shards (gfy_shard.node_ptr / edge_ptr: records never
+// share edges, graph.py:392-395, and a record's edges are one contiguous part of the edge
+// list).  With them the COO -> plans stage needs no global atomics (csr_records.inc): a
+// workgroup owns kRecRows consecutive rows of one shard and scans only the edges of the records
+// that overlap them.  `range_base`: workgroups of that stage, per shard.
+constexpr int kRecRows = 256;       // rows per workgroup: eight 32-row tiles
+struct RecordTable {
+  const int64_t* node_ptr[kMaxBatchShards];   // [records + 1], shard-local, ascending
+  const int64_t* edge_ptr[kMaxBatchShards];   // [records + 1]
+  int records[kMaxBatchShards];
+  int range_base[kMaxBatchShards + 1];
+  __device__ int shard_of_range(int block, int shards) const {
+    int s = 0;
+    for (int k = 1; k < shards; ++k) s += block >= range_base[k] ? 1 : 0;
+    return s;
+  }
+};
+
 // COO -> CSR scratch (csr_build.hip, csr_finish.inc), all in the caller's workspace
 constexpr int kCsrSlots = 8;        // edge ids kept per row in the table (= plan slots)
 constexpr int kCsrTileRows = 32;    // rows finished by one 256-thread block (= layer tile)
@@ -274,8 +292,10 @@ size_t encode_f16_workspace_bytes(int64_t n, int64_t e);
 // COO in -> embeddings out: CSR build and encode as one sequence of launches, the last CSR
 // stage fused with the per-encode setup; the workspace's first csr_clear_bytes(n) bytes must
 // be zero (they are zero again afterwards)
-int launch_encode_coo_f16(const gfy_encoder* enc, const ShardTable& shards, int out_dtype,
-                          int normalise, void* ws, size_t ws_bytes, hipStream_t s);
+// `records`: nullptr, or the record boundaries of EVERY shard of the batch
+int launch_encode_coo_f16(const gfy_encoder* enc, const ShardTable& shards,
+                          const RecordTable* records, int out_dtype, int normalise, void* ws,
+                          size_t ws_bytes, hipStream_t s);
 size_t encode_coo_f16_workspace_bytes(int64_t padded_rows, int64_t e);
 
 // one GINE layer on a given hidden state, one of its phase tensors out (parity tests)

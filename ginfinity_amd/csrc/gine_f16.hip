@@ -395,6 +395,7 @@ __global__ __launch_bounds__(256) void k_copy_rows_f16(const f16* __restrict__ s
 
 #include "csr_finish.inc"
 #include "gine_layer.inc"
+#include "csr_records.inc"
 #include "gine_layer_q.inc"
 #include "gine_block_pipe.inc"
 #include "gine_layer_w.inc"
@@ -479,6 +480,7 @@ int prepare_device_f16() {   // gfy_encoder_create, with the encoder's device cu
 // `coo` != nullptr: the CSR is finished inside the setup launch (gfy_encode_coo)
 struct CooInput {
   CsrScratch scratch;
+  const RecordTable* records;   // or nullptr: the counting kernel has filled the scratch table
   bool scan_free;
   int32_t* row_ptr;
   int32_t* col;
@@ -512,6 +514,18 @@ static int encode_f16_on(const gfy_encoder* enc, const ShardTable& shards, const
     const int linear_blocks = (int)(blocks > 2048 ? 2048 : blocks);
     if (tap_stage == 0)
       k_input_linear_f16<<<linear_blocks, 256, 0, s>>>(shards, enc->f16.w_in, enc->f16.b_in, ha);
+    else if (coo && coo->records) {   // COO -> plans by record ranges (csr_records.inc): no counting launch
+#ifdef GFY_DIAG_SETUP_SPLIT   // diagnostic: GFY_DIAG_SETUP=1 range workgroups only, 2 Linear only (wrong results)
+      static const int diag = getenv("GFY_DIAG_SETUP") ? atoi(getenv("GFY_DIAG_SETUP")) : 0;
+      const int ranges = diag == 2 ? 0 : coo->records->range_base[shards.shards];
+      const int linear = diag == 1 ? 0 : linear_blocks;
+#else
+      const int ranges = coo->records->range_base[shards.shards], linear = linear_blocks;
+#endif
+      k_encode_setup_rec<<<ranges + linear, 256, 0, s>>>(
+          shards, *coo->records, enc->f16.w_in, enc->f16.b_in, ha, coo->row_ptr, coo->col,
+          coo->typ, coo->scratch.perm, plans, ranges, enc->edge_dim);
+    }
     else if (coo && coo->scan_free)   // + last CSR stage (row offsets included) + tile plans
       k_encode_setup_coo<false><<<layer_tiles + linear_blocks, 256, 0, s>>>(
           shards, enc->f16.w_in, enc->f16.b_in, ha, coo->scratch, coo->row_ptr, coo->col,
@@ -579,7 +593,8 @@ static int encode_f16_on(const gfy_encoder* enc, const ShardTable& shards, const
   HeadOut no_out{};
   const HeadOut head_out{enc->f16.head, shards, normalise};
   for (int l = 0; l < stop; ++l) {
-    int32_t* const spent = coo && l == 0 && coo->scan_free ? coo->scratch.tile_sum : nullptr;
+    int32_t* const spent =
+        coo && l == 0 && coo->scan_free && !coo->records ? coo->scratch.tile_sum : nullptr;
     unsigned long long* const span = enc->timing == 3 ? enc->device_spans + 2 * l : nullptr;
     const bool with_head = fuse_head && l == stop - 1;
 #define GFY_LAUNCH_LAYER(RES, HEAD)                                                          \
@@ -712,8 +727,9 @@ size_t encode_coo_f16_workspace_bytes(int64_t rows, int64_t e) {
   return carve_coo(nullptr, rows, e).bytes;
 }
 
-int launch_encode_coo_f16(const gfy_encoder* enc, const ShardTable& shards, int out_dtype,
-                          int normalise, void* ws, size_t ws_bytes, hipStream_t s) {
+int launch_encode_coo_f16(const gfy_encoder* enc, const ShardTable& shards,
+                          const RecordTable* records, int out_dtype, int normalise, void* ws,
+                          size_t ws_bytes, hipStream_t s) {
   // before anything is launched (an error return must leave the workspace's counters zero): the
   // counting kernel's table keeps an edge's source row in 24 bits, 0xFFFFFF = none
   GFY_REQUIRE(shards.total_rows() < kCsrMaxRows, GFY_ERR_UNSUPPORTED,
@@ -727,10 +743,11 @@ int launch_encode_coo_f16(const gfy_encoder* enc, const ShardTable& shards, int 
   // measured: 41-46 us for the pair at 240,000 nodes against 16-22 + 17 us apart; the launch
   // holds more blocks than the chip, so the Linear's blocks only start when counting blocks
   // retire, and nothing overlaps.  profiles/README.md, round 4.)
-  if (const int rc = launch_csr_count_scan(w.scratch, w.scan_sums, shards, scan_free, w.row_ptr,
-                                           shards.total_rows(), s))
-    return rc;
-  const CooInput coo{w.scratch, scan_free, w.row_ptr, w.col, w.typ};
+  if (!records)
+    if (const int rc = launch_csr_count_scan(w.scratch, w.scan_sums, shards, scan_free, w.row_ptr,
+                                             shards.total_rows(), s))
+      return rc;
+  const CooInput coo{w.scratch, records, scan_free, w.row_ptr, w.col, w.typ};
   return encode_f16_on(enc, shards, nullptr, nullptr, nullptr, &coo, out_dtype, normalise, -1,
                        w.encode, w.encode_bytes, s);
 }

@@ -48,6 +48,34 @@ def _ptr(tensor: torch.Tensor | None) -> int | None:
     return None if tensor is None else tensor.data_ptr()
 
 
+#: a record's edge list is read by every workgroup that owns 256 of its rows: beyond this many
+#: edges in ONE record the counting kernel (global atomics, one pass over the list) is cheaper
+MAX_RECORD_EDGES = 1 << 16
+
+
+def records_pay(node_ptr: np.ndarray, edge_ptr: np.ndarray) -> bool:
+    """Whether a micro-batch's record boundaries should travel with it: every record's edge
+    list is short enough for the record-range set-up (csrc/csr_records.inc)."""
+    if len(node_ptr) < 2 or len(node_ptr) != len(edge_ptr):
+        return False
+    return int(np.diff(edge_ptr).max()) <= MAX_RECORD_EDGES
+
+
+def attach_records(edge_index: torch.Tensor, node_ptr: torch.Tensor,
+                   edge_ptr: torch.Tensor) -> torch.Tensor:
+    """Record boundaries (device int64 tensors of records + 1 entries) ride on the micro-batch's
+    edge_index tensor, so the (features, edge_index, edge_types, out_rows, out) tuples every
+    caller passes around stay what they are."""
+    assert node_ptr.dtype == torch.int64 and edge_ptr.dtype == torch.int64
+    assert node_ptr.numel() == edge_ptr.numel() >= 2
+    edge_index.gfy_records = (node_ptr, edge_ptr)
+    return edge_index
+
+
+def records_of(edge_index: torch.Tensor):
+    return getattr(edge_index, "gfy_records", None)
+
+
 class DeviceEncoder:
     """One gfy_encoder on one GPU.  Not thread-safe (docs/OPERATIONS.md:43-47
     of the reference: serialized inference per instance)."""
@@ -302,6 +330,11 @@ class DeviceEncoder:
             slot.edge_types = _ptr(et) if edges else None
             slot.out_rows = _ptr(rows)
             slot.n_nodes, slot.n_edges = nodes, edges
+            records = records_of(ei)
+            if records is not None and edges:
+                node_ptr, edge_ptr = records
+                slot.node_ptr, slot.edge_ptr = _ptr(node_ptr), _ptr(edge_ptr)
+                slot.n_records = int(node_ptr.numel()) - 1
         return array
 
     def prepare_batch_step(self, shards, *, normalise: bool = True):
@@ -446,10 +479,16 @@ class DeviceEncoder:
             return torch.from_numpy(np.ascontiguousarray(array)).to(self.device)
 
     def upload_arrays(self, node_features: np.ndarray, edge_index: np.ndarray,
-                      edge_types: np.ndarray, node_roles: np.ndarray | None) -> tuple:
+                      edge_types: np.ndarray, node_roles: np.ndarray | None, *,
+                      node_ptr: np.ndarray | None = None,
+                      edge_ptr: np.ndarray | None = None) -> tuple:
         """Host arrays of one micro-batch → ``(features, edge_index, edge_types, out_rows or
         None, kept)`` on the device: context nodes (role != 0) take part in message passing
-        and are dropped at the head's store through ``out_rows`` (api.py:253-260)."""
+        and are dropped at the head's store through ``out_rows`` (api.py:253-260).
+        ``node_ptr`` / ``edge_ptr``: the micro-batch's record boundaries (graph.py:268-271);
+        where they pay (``records_pay``) they go up too and ride on the edge_index tensor
+        (``attach_records``): the batch call then builds its tile plans without global atomics
+        (include/gfy.h, gfy_shard.node_ptr)."""
         nodes = int(node_features.shape[0])
         out_rows, kept = None, nodes
         if node_roles is not None:
@@ -460,6 +499,9 @@ class DeviceEncoder:
                 rows[~core] = -1
                 out_rows = torch.from_numpy(rows).to(self.device)
         x, ei, et = (self._upload(a) for a in (node_features, edge_index, edge_types))
+        if node_ptr is not None and edge_ptr is not None and records_pay(node_ptr, edge_ptr):
+            attach_records(ei, self._upload(np.asarray(node_ptr, dtype=np.int64)),
+                           self._upload(np.asarray(edge_ptr, dtype=np.int64)))
         return x, ei, et, out_rows, kept
 
     def encode_arrays(self, node_features: np.ndarray, edge_index: np.ndarray,

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GFY_ABI_VERSION 3
+#define GFY_ABI_VERSION 4
 
 enum gfy_status {
   GFY_OK = 0,
@@ -203,6 +203,18 @@ typedef struct gfy_shard {
   const int32_t* out_rows;   /* or NULL */
   void* out;
   int64_t n_nodes, n_edges;
+  /* Optional (ABI 4): the shard's record boundaries as GraphShard keeps them (graph.py:268-271),
+   * DEVICE arrays of n_records + 1 ascending int64 — record r owns the nodes
+   * [node_ptr[r] - node_ptr[0], node_ptr[r + 1] - node_ptr[0]) and the edges
+   * [edge_ptr[r] - edge_ptr[0], ...) of this shard, and no edge leaves its record
+   * (graph.py:392-395).  When EVERY shard of a call has them, COO -> tile plans runs without
+   * global atomics (csrc/csr_records.inc: one launch instead of two; a workgroup scans only the
+   * edges of the records that overlap its rows).  NULL / 0: the counting kernel, as before.
+   * Results are identical either way.  Pass them only where a record's edge list is short
+   * against the shard (every workgroup of a record reads the record's whole edge list).      */
+  const int64_t* node_ptr;
+  const int64_t* edge_ptr;
+  int64_t n_records;
 } gfy_shard;
 size_t gfy_encode_coo_batch_workspace_bytes(const gfy_encoder* encoder,
                                             const gfy_shard* shards_host, int n_shards);

@@ -189,3 +189,48 @@ def test_cpu_device_loads_only_the_host_library():
                                                   "libgfy_host.so")],
                             capture_output=True, text=True).stdout
     assert "NEEDED" in needed and "hip" not in needed.lower() and "hsa" not in needed.lower()
+
+
+def test_host_library_builds_without_hipcc(tmp_path, monkeypatch):
+    """``python -m ginfinity_amd.build --host-only`` needs the host compiler and nothing else: with
+    HIPCC pointing nowhere (and no hipcc on PATH) the host library still builds, and the full
+    build says which library it could not make instead of dying in a compile job."""
+    import importlib
+    import shutil
+    build = importlib.import_module("ginfinity_amd.build")
+    monkeypatch.setenv("HIPCC", str(tmp_path / "no-such-hipcc"))
+    monkeypatch.setattr(build, "_hipcc", lambda: None)
+    monkeypatch.setattr(build, "HOST_LIBRARY", tmp_path / "libgfy_host.so")
+    assert shutil.which(build.os.environ.get("CXX", "g++")), "no host compiler in this container"
+    built = build.build(host_only=True)
+    assert built == tmp_path / "libgfy_host.so" and built.stat().st_size > 10_000
+    with pytest.raises(RuntimeError, match="--host-only"):
+        build.build()          # the GPU library: a clear message, after the host library was built
+
+
+def test_cpu_device_error_text_survives_the_gpu_library():
+    """Both libraries define gfy::set_error; libgfy.so is loaded RTLD_GLOBAL.  The host library
+    binds its own copy (-Bsymbolic), so a CPU-device failure keeps its message when the GPU
+    library is already in the process.  In a fresh interpreter (load order matters)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    script = (
+        "import sys, ctypes; sys.path.insert(0, %r)\n"
+        "from ginfinity_amd import _native as native\n"
+        "gpu = native.library()\n"                       # maps libgfy.so first (no GPU needed)
+        "host = native.host_library()\n"
+        "handle = ctypes.c_void_p()\n"
+        "rc = host.gfy_host_encoder_create(b'xxxx', 4, native.GFY_F16, ctypes.byref(handle))\n"
+        "assert rc != 0\n"
+        "text = host.gfy_last_error().decode()\n"
+        "assert 'weight pack' in text, repr(text)\n"
+        "try:\n"
+        "    native.check(rc, 'gfy_host_encoder_create', host)\n"
+        "except Exception as error:\n"
+        "    assert 'weight pack' in str(error), str(error)\n"
+        "print('ok')\n" % str(root))
+    done = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True,
+                          timeout=300)
+    assert done.returncode == 0 and done.stdout.strip() == "ok", done.stderr[-2000:]

@@ -237,3 +237,68 @@ def test_records_and_device_blocks_take_the_grouped_path_too(gpu_encoder, rouski
     assert blocks.cpu().numpy().tobytes() == single.tobytes()
     assert resident.cpu().numpy().tobytes() == single.tobytes()
     assert counts == shard.core_counts and list(map(len, many)) == [700, 800]
+
+
+def _device_with_records(engine, shard):
+    """As ``_device``, with the shard's record boundaries riding on the edge_index tensor (what
+    ``Ginfinity.stage_shards`` uploads): the batch call then takes the record-range set-up."""
+    from ginfinity_amd.engine import attach_records
+    x, ei, et, rows, kept = _device(engine, shard)
+    attach_records(ei, torch.from_numpy(np.asarray(shard.node_ptr, dtype=np.int64)).to(engine.device),
+                   torch.from_numpy(np.asarray(shard.edge_ptr, dtype=np.int64)).to(engine.device))
+    return x, ei, et, rows, kept
+
+
+@pytest.mark.parametrize("kernel", [-1, 1, 5])
+def test_record_boundaries_change_nothing_but_the_launches(gpu_encoder, mixed_shards, kernel):
+    """gfy_shard.node_ptr / edge_ptr (ABI 4): COO -> tile plans by record ranges, no counting
+    launch, no global atomics (csrc/csr_records.inc).  Same bytes as the counting path, shard by
+    shard: RNA records (staged tiles only), interchange shards with hubs and more than 40 outside
+    edges per tile (direct-path tiles: CSR rows written by the range workgroups, hub rows
+    completed by the second sweep), sliced records with context rows, a one-node shard, batches
+    whose shards start at non-zero tile and edge bases, and random batches."""
+    engine = gpu_encoder._engine
+    rng = np.random.default_rng(11)
+    batches = [mixed_shards]
+    for _ in range(6):
+        shards = []
+        for _ in range(int(rng.integers(1, 6))):
+            if rng.random() < 0.4:
+                shards.append(synthetic.arbitrary_shard(
+                    int(rng.integers(0, 1000)), nodes=int(rng.integers(300, 20000)),
+                    edges=int(rng.integers(1000, 90000)), records=int(rng.integers(1, 9)),
+                    hub_degree=int(rng.integers(1, 70))))
+            else:
+                shards.append(synthetic.roofline_shard(
+                    int(rng.integers(0, 1000)), records=int(rng.integers(1, 20)),
+                    length=int(rng.choice([34, 64, 254, 258, 500, 4000]))))
+        batches.append(shards)
+    try:
+        engine.set_option(native.GFY_OPT_LAYER_KERNEL, kernel)
+        for shards in batches:
+            plain = [o.cpu().numpy() for o in
+                     engine.encode_coo_batch([_device(engine, s) for s in shards])]
+            ranged = [o.cpu().numpy() for o in
+                      engine.encode_coo_batch([_device_with_records(engine, s) for s in shards])]
+            # ... and again on the same inputs: the workspace's counters were left zero
+            for a, b, shard in zip(plain, ranged, shards):
+                assert a.shape == b.shape
+                assert a.tobytes() == b.tobytes(), (shard.node_count, shard.record_count)
+    finally:
+        engine.set_option(native.GFY_OPT_LAYER_KERNEL, -1)
+
+
+def test_record_boundaries_and_counting_calls_share_one_workspace(gpu_encoder):
+    """A call with record boundaries leaves the counting scratch untouched (zero), so calls of
+    both kinds may alternate on one encoder workspace (encode_coo_group)."""
+    engine = gpu_encoder._engine
+    shards = [synthetic.roofline_shard(21, records=3, length=700), synthetic.arbitrary_shard(5)]
+    want = [o.cpu().numpy() for o in engine.encode_coo_batch([_device(engine, s) for s in shards])]
+    for with_records in (True, False, True, True, False):
+        outs = [torch.empty((int(np.count_nonzero(s.node_roles == 0)), 128), dtype=torch.float16,
+                            device=engine.device) for s in shards]
+        make = _device_with_records if with_records else _device
+        engine.encode_coo_group([(*make(engine, s)[:4], out) for s, out in zip(shards, outs)])
+        torch.cuda.synchronize()
+        for a, b in zip(outs, want):
+            assert a.cpu().numpy().tobytes() == b.tobytes()
