@@ -162,8 +162,9 @@ def launch_ranks(args: argparse.Namespace) -> "NoReturn":
 
 
 KERNEL_SOURCES = ("ginfinity_amd/csrc/gine_layer.inc", "ginfinity_amd/csrc/gine_layer_q.inc",
-                  "ginfinity_amd/csrc/gine_layer_w.inc", "ginfinity_amd/csrc/gine_f16.hip",
-                  "ginfinity_amd/csrc/gfy_common.h")
+                  "ginfinity_amd/csrc/gine_layer_w.inc", "ginfinity_amd/csrc/gine_block_pipe.inc",
+                  "ginfinity_amd/csrc/gine_layer_x.inc", "ginfinity_amd/csrc/csr_records.inc",
+                  "ginfinity_amd/csrc/gine_f16.hip", "ginfinity_amd/csrc/gfy_common.h")
 
 
 def kernel_source_sha16() -> str:
@@ -196,6 +197,28 @@ def measured_traffic(kernel: str, nodes_per_launch: int):
             continue
     return None, ("none: no committed PMC pass matches the kernel source as it is now "
                   "(tools/profile_round.sh + tools/pmc_summary.py)")
+
+
+def measured_counters(kernel: str):
+    """Matrix-pipe busy share and vector / matrix co-execution share of a launch of ``kernel``
+    from the committed SQ counter passes (SQ_VALU_MFMA_BUSY_CYCLES, SQ_VALU_MFMA_COEXEC_CYCLES
+    and SQ_WAVE_CYCLES over tools/gfy_bench; tools/profile_round.sh + tools/pmc_summary.py),
+    hash-guarded like ``measured_traffic``: ``(mfma_busy_frac, coexec_frac, source)``."""
+    newest = sorted((ROOT / "profiles").glob("r*_layer_sq_pmc.json"))
+    for path in reversed(newest):
+        try:
+            summary = json.loads(path.read_text())
+            if summary.get("kernel_source_sha16") != kernel_source_sha16():
+                continue
+            counters = summary["kernels"][kernel]
+            return (counters["mfma_busy_frac"], counters["coexec_frac"],
+                    f"profiles/{path.name}: rocprofv3 --pmc passes of the same kernel source "
+                    "(hash-checked), taken in a separate run; shares of the launch's cycles per "
+                    "SIMD (wave lifetime from SQ_WAVE_CYCLES)")
+        except (OSError, KeyError, ValueError, TypeError):
+            continue
+    return None, None, ("none: no committed SQ counter pass matches the kernel source as it is "
+                        "now (tools/profile_round.sh + tools/pmc_summary.py)")
 
 
 def cpu_baseline(seconds: float) -> dict:
@@ -558,33 +581,41 @@ def main() -> None:
         torch.cuda.synchronize(device)
         alone_call_ms = e0.elapsed_time(e1) / rounds
         plain = plain_layers(mean)
-        one_round = full * NODES <= 256 * 8 * 32        # a CU gets at most one round of tiles
-        kernel_name = "k_gine_layer_f16" if one_round else "k_gine_layer_w"
+        # the kernel the encoder actually launched (a checkpoint with edge_dim > 12 or a forced
+        # GFY_OPT_LAYER_KERNEL runs another one than this run's sizes suggest)
+        kernel_name = {1: "k_gine_layer_f16", 3: "k_gine_layer_q", 4: "k_gine_layer_w",
+                       5: "k_gine_layer_x"}.get(engine.last_layer_kernel(), "k_gine_layer_w")
         traffic, traffic_source = measured_traffic(kernel_name, full * NODES)
+        mfma_busy, coexec, counter_source = measured_counters(kernel_name)
+        # `frac` / `achieved` / `kernel_ms`: ONE launch by itself — what a profiler reports for
+        # the kernel and what profiles/ holds.  The span of a launch while another batch's
+        # kernels share the CUs is kept aside (`in_flight`): it contains the others' work.
         roofline = {
             "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "kernel": kernel_name, "shards_per_launch": full,
             "algorithmic_bytes_per_launch": launch_bytes,
-            "configuration": f"{lanes} batch(es) of {full} shard(s) in flight on {lanes} "
-                             "stream(s), as timed; kernel_ms = device clock, first workgroup "
-                             "start to last end (what rocprofv3 reports as the kernel's duration)",
-            "note": ("with several streams in flight the workgroups of different batches' "
-                     "kernels share the CUs, so a launch's span contains the others' work: "
-                     "`isolated` is the kernel by itself, `pipeline_frac` the whole step"
-                     if lanes > 1 else "one batch at a time: the span is the kernel by itself"),
-            **layer_roofline(timed_ms),
+            "configuration": "one batch at a time, one HIP event pair around the plain layer "
+                             "launches (the kernel by itself: rocprofv3's average duration of "
+                             "the same command is committed under profiles/)",
+            **layer_roofline(sum(plain) / len(plain)),
             "traffic": traffic, "traffic_source": traffic_source,
-            "isolated": {"configuration": "one batch at a time, one HIP event pair around the "
-                                          "plain layer launches",
-                         **layer_roofline(sum(plain) / len(plain))},
+            "mfma_busy_frac": mfma_busy, "coexec_frac": coexec, "counter_source": counter_source,
+            "isolated": layer_roofline(sum(plain) / len(plain)),
+            "in_flight": {"configuration": f"{lanes} batch(es) of {full} shard(s) in flight on "
+                                           f"{lanes} stream(s), as timed; kernel_ms = device "
+                                           "clock, first workgroup start to last end: with "
+                                           "several streams the span contains the other "
+                                           "batches' workgroups",
+                          **layer_roofline(timed_ms)},
             "pipeline_frac": PIPELINE_BYTES * world * args.steps / elapsed / 1e9
                              / (HBM_PEAK_GBS * world),
             "pipeline_frac_long": (PIPELINE_BYTES * world * args.steps * repeats / long_elapsed
                                    / 1e9 / (HBM_PEAK_GBS * world)) if repeats else None,
         }
         kernels = {"configuration": f"one batch of {full} shard(s) at a time on one stream "
-                                    "(gfy_encode_coo_batch: k_csr_count, k_encode_setup_coo, "
-                                    "4 layer launches, the last with head + normalise)",
+                                    "(gfy_encode_coo_batch: k_encode_setup_rec — or k_csr_count + "
+                                    "k_encode_setup_coo without record boundaries —, 4 layer "
+                                    "launches, the last with head + normalise)",
                    "whole_call_ms": alone_call_ms, "per_shard_ms": alone_call_ms / full,
                    "csr_finish_plans_input_linear_ms": mean[0], "layer_ms": plain,
                    "last_layer_with_head_normalise_ms": mean[-2]}

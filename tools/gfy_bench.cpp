@@ -57,7 +57,9 @@ int main(int argc, char** argv) {
   // graph: records of L nodes: backbone both ways, skip2 both ways, random matching both ways
   const int64_t recs = N / L;
   std::vector<int32_t> src, dst; std::vector<uint8_t> typ;
+  std::vector<int64_t> node_ptr(recs + 1), edge_ptr(recs + 1);   // record boundaries (gfy_shard, ABI 4)
   for (int64_t r = 0; r < recs; ++r) {
+    node_ptr[r] = r * L; edge_ptr[r] = (int64_t)src.size();
     int32_t b = (int32_t)(r * L);
     for (int i = 0; i + 1 < L; ++i) { src.push_back(b + i); dst.push_back(b + i + 1); typ.push_back(0); }
     for (int i = 0; i + 1 < L; ++i) { src.push_back(b + i + 1); dst.push_back(b + i); typ.push_back(1); }
@@ -69,8 +71,11 @@ int main(int argc, char** argv) {
                                       src.push_back(b + i + 2); dst.push_back(b + i); typ.push_back(5); }
     for (int i = 0; i < 6; ++i) { src.push_back(b + rng() % L); dst.push_back(b + rng() % L); typ.push_back(2); }
   }
+  node_ptr[recs] = N; edge_ptr[recs] = (int64_t)src.size();   // (N % L trailing nodes: isolated, in the last record)
   if (no_edges) { src.resize(1); dst.resize(1); typ.resize(1); }
   const int64_t E = (int64_t)src.size();
+  // GFY_BENCH_RECORDS=0: the COO calls go without record boundaries (k_csr_count + k_encode_setup_coo)
+  const bool with_records = !no_edges && !(getenv("GFY_BENCH_RECORDS") && atoi(getenv("GFY_BENCH_RECORDS")) == 0);
   std::vector<int32_t> ei(2 * E);
   memcpy(ei.data(), src.data(), E * 4); memcpy(ei.data() + E, dst.data(), E * 4);
   std::vector<float> x(N * 7);
@@ -105,18 +110,33 @@ int main(int argc, char** argv) {
   CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
   CK(hipEventElapsedTime(&ms, e0, e1));
   printf("encode only: %.1f us/step\n", 1e3 * ms / steps);
-  // the whole seam as one call (gfy_encode_coo): 3 + 4 launches on a workspace cleared once
-  const size_t b3 = gfy_encode_coo_workspace_bytes(enc, N, E);
+  // the whole seam as one call (gfy_encode_coo_batch of one shard, with its record boundaries:
+  // 1 + 4 launches; without them gfy_encode_coo's 2 + 4) on a workspace cleared once
+  int64_t *dnp = nullptr, *dep = nullptr;
+  CK(hipMalloc(&dnp, (recs + 1) * 8)); CK(hipMalloc(&dep, (recs + 1) * 8));
+  CK(hipMemcpy(dnp, node_ptr.data(), (recs + 1) * 8, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dep, edge_ptr.data(), (recs + 1) * 8, hipMemcpyHostToDevice));
+  auto shard_of = [&](void* out) {
+    gfy_shard one{};
+    one.node_features = dx; one.edge_index = dei; one.edge_types = det; one.out = out;
+    one.n_nodes = N; one.n_edges = E;
+    if (with_records) { one.node_ptr = dnp; one.edge_ptr = dep; one.n_records = recs; }
+    return one;
+  };
+  auto encode_coo = [&](gfy_encoder* which, void* out, void* ws, size_t bytes, hipStream_t on) {
+    const gfy_shard one = shard_of(out);
+    GK(gfy_encode_coo_batch(which, &one, 1, GFY_F16, 1, ws, bytes, on));
+  };
+  const gfy_shard probe = shard_of(dout);
+  const size_t b3 = gfy_encode_coo_batch_workspace_bytes(enc, &probe, 1);
   void* ws3; CK(hipMalloc(&ws3, b3)); CK(hipMemsetAsync(ws3, 0, b3, s));
-  for (int i = 0; i < 20; ++i)
-    GK(gfy_encode_coo(enc, dx, dei, det, N, E, nullptr, dout, GFY_F16, 1, ws3, b3, s));
+  for (int i = 0; i < 20; ++i) encode_coo(enc, dout, ws3, b3, s);
   CK(hipStreamSynchronize(s));
   CK(hipEventRecord(e0, s));
-  for (int i = 0; i < steps; ++i)
-    GK(gfy_encode_coo(enc, dx, dei, det, N, E, nullptr, dout, GFY_F16, 1, ws3, b3, s));
+  for (int i = 0; i < steps; ++i) encode_coo(enc, dout, ws3, b3, s);
   CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
   CK(hipEventElapsedTime(&ms, e0, e1));
-  printf("gfy_encode_coo: %.1f us/step  -> %.1f M nodes/s\n", 1e3 * ms / steps, N * steps / ms / 1e3);
+  printf("gfy_encode_coo%s: %.1f us/step  -> %.1f M nodes/s\n", with_records ? " (record boundaries)" : "", 1e3 * ms / steps, N * steps / ms / 1e3);
   const int max_lanes = getenv("GFY_BENCH_STREAMS") ? atoi(getenv("GFY_BENCH_STREAMS")) : 4;
   for (int lanes = 2; lanes <= max_lanes; lanes += lanes < 4 ? 1 : 2) {  // independent shards in flight on several streams
     std::vector<gfy_encoder*> encs(lanes); std::vector<hipStream_t> ss(lanes);
@@ -130,7 +150,7 @@ int main(int argc, char** argv) {
     }
     auto step = [&](int i) {
       const int q = i % lanes;
-      GK(gfy_encode_coo(encs[q], dx, dei, det, N, E, nullptr, outs[q], GFY_F16, 1, wb[q], b3, ss[q]));
+      encode_coo(encs[q], outs[q], wb[q], b3, ss[q]);
     };
     const int many = steps * lanes;   // the same time in flight as the one-stream loop
     for (int i = 0; i < many / 2; ++i) step(i);

@@ -18,7 +18,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define PKADD(j) asm volatile("v_pk_add_f16 %0, %0, %1" : "+v"(b[j]) : "v"(hone));
 #define MIX(j) asm volatile("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel_hi:[1,0,0]" : "+v"(a[j]) : "v"(b[j]));
 #define NOP asm volatile("s_nop 0");
-#define SALU asm volatile("s_add_u32 %0, %0, 1" : "+s"(sreg));
+#define SALU asm volatile("s_add_u32 %0, %0, 1" : "+s"(sreg) : : "scc");
 #define LDSR(j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ld[j]) : "v"(lds_addr), "n"((j) * 1024));
 #define WAIT(n) asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(n));
 

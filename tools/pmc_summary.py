@@ -24,7 +24,7 @@ def short(name: str) -> str:
     base = m.group(1)
     if base == "k_gine_layer_f16" and re.search(r"k_gine_layer_f16ILb[01]ELb1E", name):
         base = "k_gine_layer_f16<+head>"          # <kResidual, kHead>
-    if base in ("k_gine_layer_q", "k_gine_layer_w") and re.search(
+    if base in ("k_gine_layer_q", "k_gine_layer_w", "k_gine_layer_x") and re.search(
             base + r"ILb[01]ELb[01]ELb1E", name):
         base += "<+head>"                         # <kResidual, kTap, kHead>
     return base
@@ -73,15 +73,34 @@ json.dump({
     "kernels": traffic}, open(root / "profiles" / f"{tag}_traffic_pmc.json", "w"), indent=1)
 
 sq = collections.defaultdict(dict)
-for sub in ("sq_a", "sq_b"):
+for sub in ("sq_a", "sq_b", "sq_c", "sq_a_k5", "sq_c_k5", "sq_a_k3", "sq_c_k3"):
     path = src / sub / "sq_counter_collection.csv"
     if path.exists():
         for kernel, counters in means(path).items():
             sq[kernel].update(counters)
+SIMDS = 1024
+for kernel, c in sq.items():
+    # shares of the launch's cycles per SIMD.  The launch's length in shader cycles is taken as
+    # the mean wave lifetime (SQ_WAVE_CYCLES counts quad-cycles per wave; a layer launch's waves
+    # live from its start to its end, within a few per cent), the busy counters are cycles
+    # summed over the chip's 1,024 SIMDs.
+    if c.get("SQ_WAVES") and c.get("SQ_WAVE_CYCLES") and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+        lifetime = 4.0 * c["SQ_WAVE_CYCLES"] / c["SQ_WAVES"]
+        c["wave_lifetime_cycles"] = lifetime
+        c["mfma_busy_frac"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / SIMDS / lifetime
+        if "SQ_VALU_MFMA_COEXEC_CYCLES" in c:
+            c["coexec_frac"] = c["SQ_VALU_MFMA_COEXEC_CYCLES"] / SIMDS / lifetime
+        if "SQ_ACTIVE_INST_VALU" in c:   # quad-cycles: one per vector instruction (incl. MFMA issue)
+            c["valu_active_frac"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / SIMDS / lifetime
 json.dump({
-    "how": "two rocprofv3 --pmc passes of 8 SQ counters over ./tools/gfy_bench 240000 20; mean per "
-           "dispatch, summed over the chip (SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count "
-           "quad-cycles per wave, SQ_VALU_MFMA_BUSY_CYCLES and SQ_LDS_* count cycles)",
+    "how": "rocprofv3 --pmc passes of <= 8 SQ counters each over ./tools/gfy_bench 240000 20 "
+           "(tools/profile_round.sh: sq_a, sq_b, sq_c for the default kernel, _k5 / _k3 with "
+           "GFY_BENCH_LAYER_KERNEL=5 / 3); mean per dispatch, summed over the chip "
+           "(SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles per wave, "
+           "SQ_VALU_MFMA_BUSY_CYCLES, SQ_VALU_MFMA_COEXEC_CYCLES and SQ_LDS_* count cycles); "
+           "*_frac: shares of the launch's cycles per SIMD (1,024 SIMDs, launch length = mean "
+           "wave lifetime)",
+    "kernel_source_sha16": kernel_source_sha16(),
     "kernels": sq}, open(root / "profiles" / f"{tag}_layer_sq_pmc.json", "w"), indent=1)
 pairwise = src / "sq_pairwise" / "sq_counter_collection.csv"
 if pairwise.exists():

@@ -41,6 +41,25 @@ GFY_BENCH_STREAMS=1 timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYC
 GFY_BENCH_STREAMS=1 timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM SQ_INSTS_MFMA \
   --kernel-trace -d $OUT/sq_b -o sq --output-format csv -- $R/tools/gfy_bench 240000 20 > $OUT/sq_b.log 2>&1 || exit 1
 
+# 4b. what the occupancy / overlap question is about: cycles in which vector and matrix
+#     instructions execute together (MI355X_MICROARCH.md, "Two waves per SIMD", item 9), with the
+#     wave count that turns SQ_WAVE_CYCLES into a launch length — for the default kernel, the
+#     three-workgroup kernel (5) and the persistent rounds (3)
+SQC="SQ_VALU_MFMA_COEXEC_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU"
+GFY_BENCH_STREAMS=1 timeout -k 10 200 rocprofv3 --pmc $SQC --kernel-trace -d $OUT/sq_c -o sq --output-format csv -- $R/tools/gfy_bench 240000 20 > $OUT/sq_c.log 2>&1 || exit 1
+for K in 5 3; do
+  GFY_BENCH_LAYER_KERNEL=$K GFY_BENCH_STREAMS=1 timeout -k 10 200 rocprofv3 --pmc $SQC --kernel-trace -d $OUT/sq_c_k$K -o sq --output-format csv -- $R/tools/gfy_bench 240000 20 > $OUT/sq_c_k$K.log 2>&1 || exit 1
+  GFY_BENCH_LAYER_KERNEL=$K GFY_BENCH_STREAMS=1 timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS \
+    --kernel-trace -d $OUT/sq_a_k$K -o sq --output-format csv -- $R/tools/gfy_bench 240000 20 > $OUT/sq_a_k$K.log 2>&1 || exit 1
+done
+# ... the same kernels' durations on this box, back to back (boxes differ by +-5 %)
+for K in 4 5 3 1; do
+  GFY_BENCH_LAYER_KERNEL=$K timeout -k 10 100 $R/tools/gfy_bench 240000 100 > $OUT/gfy_bench_k$K.txt 2>&1 || exit 1
+done
+timeout -k 10 120 $R/tools/mlp_probe 200 > $OUT/mlp_probe.txt 2>&1 || exit 1
+timeout -k 10 120 $R/tools/issue_probe > $OUT/issue_probe.txt 2>&1 || exit 1
+GFY_BENCH_LAYER_KERNEL=5 GFY_BENCH_STREAMS=1 timeout -k 10 100 $R/tools/gfy_bench_stamps 240000 50 > $OUT/gfy_bench_stamps_k5.txt 2>&1 || exit 1
+
 # 5. C++ driver (no Python in the loop) and in-kernel phase stamps (diagnostic build)
 timeout -k 10 100 $R/tools/gfy_bench 240000 200 > $OUT/gfy_bench.txt 2>&1 || exit 1
 GFY_BENCH_STREAMS=1 timeout -k 10 100 $R/tools/gfy_bench_stamps 240000 50 > $OUT/gfy_bench_stamps.txt 2>&1 || exit 1
