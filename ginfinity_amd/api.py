@@ -681,7 +681,9 @@ class Ginfinity:
                     packed, kept = jobs[index].result()
                     features, edge_index, edge_types, out_rows, node_ptr, edge_ptr = \
                         uploader.send(packed, mapped=direct)
-                    if node_ptr is not None:
+                    # mapped inputs are read over PCIe: the record-range set-up reads a record's
+                    # destinations once per 256 of its rows, the counting kernel every array once
+                    if node_ptr is not None and not direct:
                         attach_records(edge_index, node_ptr, edge_ptr)
                     members.append((packed, (features, edge_index, edge_types, out_rows,
                                              device_rows[first_row:first_row + kept])))

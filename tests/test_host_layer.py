@@ -442,3 +442,28 @@ def test_whole_shard_window_extraction_equals_the_per_record_builder(rouskin_rec
             want.identifiers, want.sequences, want.structures)
         if keep:
             assert (got.node_roles != 0).any()
+
+
+def test_record_boundaries_ride_on_the_edge_index_tensor():
+    """``gfy_shard.node_ptr / edge_ptr`` (ABI 4): the Python layer passes a micro-batch's record
+    boundaries by attaching them to its edge_index tensor, and only where a record's edge list is
+    short against what every 256-row workgroup of the record would have to scan."""
+    import torch
+    from ginfinity_amd import _native as native
+    from ginfinity_amd.engine import MAX_RECORD_EDGES, attach_records, records_of, records_pay
+    node_ptr = np.array([0, 4000, 8000, 8064], dtype=np.int64)
+    edge_ptr = np.array([0, 20000, 40000, 40300], dtype=np.int64)
+    assert records_pay(node_ptr, edge_ptr)
+    assert not records_pay(node_ptr, np.array([0, MAX_RECORD_EDGES + 1, MAX_RECORD_EDGES + 2,
+                                               MAX_RECORD_EDGES + 3], dtype=np.int64))
+    assert not records_pay(node_ptr[:1], edge_ptr[:1])            # no record at all
+    assert not records_pay(node_ptr, edge_ptr[:-1])               # inconsistent lengths
+    edge_index = torch.zeros((2, 5), dtype=torch.int32)
+    assert records_of(edge_index) is None
+    attach_records(edge_index, torch.from_numpy(node_ptr), torch.from_numpy(edge_ptr))
+    attached = records_of(edge_index)
+    assert attached is not None and attached[0].dtype == torch.int64
+    assert int(attached[0].numel()) - 1 == 3
+    # the descriptor the C ABI takes has the three optional fields at its end (ABI 4)
+    names = [name for name, _kind in native.GfyShard._fields_]
+    assert names[-3:] == ["node_ptr", "edge_ptr", "n_records"] and native.ABI_VERSION == 4

@@ -1,16 +1,18 @@
 #!/bin/bash
 # Reproduce the committed measurement set of a round on a GPU box:
 #   python -m ginfinity_amd.build && python -m ginfinity_amd.build --stamps && bash tools/build_tools.sh
-#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/profile_round.sh r02'
+#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/profile_round.sh r05 a'   (then ... r05 b)
 # Writes gpurun_out/<tag>/…; `python tools/pmc_summary.py <tag>` condenses the counter passes
 # and the summaries judged are then copied into profiles/ (see profiles/README.md).
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r05}
+PART=${2:-all}     # "a": bench lines, kernel traces, counter passes; "b": drivers, stamps, distance, API; "all"
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 
+if [ "$PART" != "b" ]; then
 # 1. bench lines: the default (batches of 4 shards, 2 in flight), one batch at a time, and one
 #    SHARD at a time (single-round launches: the round-2 kernel with the fused head)
 timeout -k 10 400 python3 $R/bench.py --steps 960 --warmup 96 > $OUT/bench_line.json 2> $OUT/bench_line.err || exit 1
@@ -60,6 +62,8 @@ timeout -k 10 120 $R/tools/mlp_probe 200 > $OUT/mlp_probe.txt 2>&1 || exit 1
 timeout -k 10 120 $R/tools/issue_probe > $OUT/issue_probe.txt 2>&1 || exit 1
 GFY_BENCH_LAYER_KERNEL=5 GFY_BENCH_STREAMS=1 timeout -k 10 100 $R/tools/gfy_bench_stamps 240000 50 > $OUT/gfy_bench_stamps_k5.txt 2>&1 || exit 1
 
+fi
+if [ "$PART" != "a" ]; then
 # 5. C++ driver (no Python in the loop) and in-kernel phase stamps (diagnostic build)
 timeout -k 10 100 $R/tools/gfy_bench 240000 200 > $OUT/gfy_bench.txt 2>&1 || exit 1
 GFY_BENCH_STREAMS=1 timeout -k 10 100 $R/tools/gfy_bench_stamps 240000 50 > $OUT/gfy_bench_stamps.txt 2>&1 || exit 1
@@ -77,4 +81,5 @@ timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ
 
 # 7. API level incl. PCIe (config 2) and shard file -> embeddings
 timeout -k 10 300 python3 $R/tools/bench_api.py > $OUT/api_bench.json 2> $OUT/api.err || exit 1
+fi
 echo done
