@@ -6,7 +6,7 @@
 # and the summaries judged are then copied into profiles/ (see profiles/README.md).
 set -o pipefail
 TAG=${1:-r05}
-PART=${2:-all}     # "a": bench lines, kernel traces, counter passes; "b": drivers, stamps, distance, API; "all"
+PART=${2:-all}     # "a": bench lines, kernel traces, counter passes; "lines": the bench lines only; "b": drivers, stamps, distance, API; "all"
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -21,6 +21,7 @@ timeout -k 10 200 python3 $R/bench.py --steps 960 --warmup 96 --streams 1 --batc
 # ... and what the driver runs (20 steps, 5 warm-up): the repeated leg covers >= 10 ms
 timeout -k 10 200 python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --distance-rows 0 > $OUT/bench_driver_line.json 2>> $OUT/bench_line.err || exit 1
 
+[ "$PART" = "lines" ] && { echo done; exit 0; }   # "lines": the bench lines only (after pmc_summary.py has refreshed the counter files they quote)
 # 2. per-kernel durations of the same commands (kernel trace + stats only)
 for S in 1 2; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/kt$S -o kt --output-format csv -- \
