@@ -28,6 +28,7 @@ from __future__ import annotations
 
 from concurrent.futures import ThreadPoolExecutor
 import collections
+import os
 import queue
 import threading
 
@@ -148,7 +149,9 @@ def _settle(jobs) -> None:
 
 #: packer threads of an encoder (numpy releases the GIL in the copies they make); one per
 #: staging slot of the uploader's ring at most
-_PACKERS = 8
+_PACKERS = int(os.environ.get("GFY_PACKERS", "8"))
+#: staging slots of an uploader's ring (micro-batches packed ahead of the launching thread)
+_STAGING_SLOTS = int(os.environ.get("GFY_STAGING_SLOTS", "8"))
 
 #: default mode only: results alive beyond this many page-locked bytes go to pageable memory
 PINNED_RESULT_LIMIT = 4 << 30
@@ -315,7 +318,8 @@ class _Uploader:
     _TORCH = {np.dtype(np.uint8): torch.uint8, np.dtype(np.int64): torch.int64,
               np.dtype(np.int32): torch.int32, np.dtype(np.float32): torch.float32}
 
-    def __init__(self, device: torch.device, slots: int = 8) -> None:
+    def __init__(self, device: torch.device, slots: int | None = None) -> None:
+        slots = _STAGING_SLOTS if slots is None else slots
         self._device = device
         self._staging: list[torch.Tensor | None] = [None] * slots
         self._copied: list["torch.cuda.Event | None"] = [None] * slots
@@ -392,6 +396,57 @@ class _Uploader:
             flat = on_device[offset:offset + array.nbytes].view(self._TORCH[array.dtype])
             views.append(flat.view(array.shape))
         return views
+
+    # -- a GROUP of micro-batches in one slot: one H2D copy, one event per group -----------------
+    @staticmethod
+    def padded(nbytes: int) -> int:
+        return -(-nbytes // 256) * 256
+
+    def prepare_slot(self, slot: int, total: int) -> None:
+        """Launching thread, before the group's packers are submitted: the slot's last copy has
+        left it and its staging buffer holds ``total`` bytes."""
+        if self._copied[slot] is not None:
+            self._copied[slot].synchronize()
+        staging = self._staging[slot]
+        if staging is None or staging.numel() < total:
+            self._staging[slot] = torch.empty(max(total, 1 << 20), dtype=torch.uint8,
+                                              pin_memory=True)
+
+    def pack_at(self, slot: int, base: int, arrays: Sequence) -> list[int]:
+        """``pack`` into a prepared slot at byte ``base`` (packer threads; the ranges of a
+        group's micro-batches are disjoint): the offsets of the arrays inside the slot."""
+        rebases = [item[1:] if isinstance(item, tuple) else None for item in arrays]
+        arrays = [item[0] if isinstance(item, tuple) else item for item in arrays]
+        host = self._staging[slot].numpy()
+        offsets, at = [], base
+        for array, rebase in zip(arrays, rebases):
+            offsets.append(at)
+            if array is None:
+                continue
+            if array.nbytes:
+                target = host[at:at + array.nbytes].view(array.dtype).reshape(array.shape)
+                if rebase is None:
+                    np.copyto(target, array)
+                else:
+                    shift, low, high = rebase
+                    if shift:
+                        np.subtract(array, shift, out=target)
+                    else:
+                        np.copyto(target, array)
+                    if target.size and int(target.view(np.uint32).max()) >= high - low:
+                        raise GraphValidationError("edge index outside shard node range")
+            at += self.padded(array.nbytes)
+        return offsets
+
+    def send_range(self, slot: int, total: int) -> torch.Tensor:
+        """Bytes [0, total) of a packed slot → ONE device allocation by one asynchronous copy on
+        the current stream."""
+        block = torch.empty(max(total, 1), dtype=torch.uint8, device=self._device)
+        block[:total].copy_(self._staging[slot][:total], non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(self._device))
+        self._copied[slot] = done
+        return block
 
     def hold(self, packed, event: "torch.cuda.Event") -> None:
         """The slot of ``packed`` (sent ``mapped``) is read by the device until ``event``."""
@@ -743,6 +798,41 @@ class Ginfinity:
             shard.edge_types[e0:e1], rows, node_ptr, edge_ptr))
         return packed, kept
 
+    @staticmethod
+    def _microbatch_bytes(shard: GraphShard, start: int, stop: int) -> int:
+        """Staging bytes of records [start, stop) as ``_pack_microbatch_at`` lays them out."""
+        n = int(shard.node_ptr[stop]) - int(shard.node_ptr[start])
+        e = int(shard.edge_ptr[stop]) - int(shard.edge_ptr[start])
+        pad = _Uploader.padded
+        total = pad(n * shard.node_features.shape[1] * 4) + pad(2 * e * 4) + pad(e)
+        total += pad(n * 4)                                   # out_rows (used or not)
+        total += 2 * pad((stop - start + 1) * 8)              # node_ptr, edge_ptr (used or not)
+        return total
+
+    @staticmethod
+    def _pack_microbatch_at(uploader: "_Uploader", slot: int, base: int, shard: GraphShard,
+                            start: int, stop: int):
+        """``_pack_microbatch`` into a prepared group slot at byte ``base``: ``(offsets of the six
+        arrays in the slot — 0 where an array is absent —, nodes, edges, records or 0, kept)``."""
+        n0, n1 = int(shard.node_ptr[start]), int(shard.node_ptr[stop])
+        e0, e1 = int(shard.edge_ptr[start]), int(shard.edge_ptr[stop])
+        roles = shard.node_roles[n0:n1]
+        rows, kept = None, n1 - n0
+        if roles.any():
+            core = roles == 0
+            kept = int(np.count_nonzero(core))
+            rows = np.cumsum(core, dtype=np.int32) - np.int32(1)
+            rows[~core] = -1
+        node_ptr = edge_ptr = None
+        if records_pay(shard.node_ptr[start:stop + 1], shard.edge_ptr[start:stop + 1]):
+            node_ptr, edge_ptr = shard.node_ptr[start:stop + 1], shard.edge_ptr[start:stop + 1]
+        arrays = (shard.node_features[n0:n1], (shard.edge_index[:, e0:e1], np.int32(n0), n0, n1),
+                  shard.edge_types[e0:e1], rows, node_ptr, edge_ptr)
+        offsets = uploader.pack_at(slot, base, arrays)
+        present = (True, True, True, rows is not None, node_ptr is not None, edge_ptr is not None)
+        return ([offset if here else -1 for offset, here in zip(offsets, present)],
+                n1 - n0, e1 - e0, stop - start if node_ptr is not None else 0, kept)
+
     def _device_rows(self, rows: int, torch_dtype: torch.dtype) -> torch.Tensor:
         """[rows, 128] of ``torch_dtype`` on the device, a view of ONE block the encoder keeps
         (grown when a call needs more): the micro-batches of a call write their embeddings into
@@ -908,37 +998,52 @@ class Ginfinity:
             self._copy_stream = torch.cuda.Stream(device=device)
         uploader, copies = self._uploader, self._copy_stream
         compute = torch.cuda.current_stream(device)
-        assert MICROBATCH_GROUP <= uploader.slots
-        jobs: list = []
+        # A GROUP of micro-batches shares one staging slot, one H2D copy and one event: per
+        # micro-batch the launching thread then only hands four packers their byte ranges and
+        # turns offsets into addresses (one copy and one event per micro-batch were ~50 us each
+        # of this thread: 128 micro-batches could not start faster than one per 180 us).
+        groups = list(_groups(len(plan)))
+        submitted: list = []              # per group: (slot, total bytes, [jobs])
+
+        def submit(group) -> None:
+            slot, at, jobs_of = uploader.reserve(), 0, []
+            bases = []
+            for index in group:
+                shard, a, b = plan[index]
+                bases.append(at)
+                at += self._microbatch_bytes(shard, a, b)
+            uploader.prepare_slot(slot, at)
+            for index, base in zip(group, bases):
+                shard, a, b = plan[index]
+                jobs_of.append(self._preparer.submit(self._pack_microbatch_at, uploader, slot, base,
+                                                     shard, a, b))
+            submitted.append((slot, at, jobs_of))
+
         first = 0
+        ahead = max(1, uploader.slots - 1)   # groups packed ahead of the one being launched
         try:
-            for group in _groups(len(plan)):
-                # (a staging slot is free again once its H2D copy has left it: `pack` waits for
-                # the event `send` records on the copy stream)
-                while len(jobs) < len(plan) and len(jobs) < group.start + uploader.slots:
-                    shard, a, b = plan[len(jobs)]
-                    jobs.append(self._preparer.submit(self._pack_microbatch, uploader,
-                                                      uploader.reserve(), shard, a, b))
-                members = []
+            for number, group in enumerate(groups):
+                while len(submitted) < len(groups) and len(submitted) <= number + ahead - 1:
+                    submit(groups[len(submitted)])
+                slot, total, jobs_of = submitted[number]
+                packed = [job.result() for job in jobs_of]
                 with torch.cuda.stream(copies):
-                    for index in group:
-                        packed, kept = jobs[index].result()
-                        views = uploader.send(packed)
-                        for view in views:
-                            if view is not None:     # allocated on the copy stream, read on
-                                view.record_stream(compute)   # the compute stream
-                        features, edge_index, edge_types, out_rows, node_ptr, edge_ptr = views
-                        if node_ptr is not None:
-                            attach_records(edge_index, node_ptr, edge_ptr)
-                        members.append((features, edge_index, edge_types, out_rows,
-                                        block[first:first + kept]))
-                        first += kept
-                    uploaded = torch.cuda.Event()
+                    inputs = uploader.send_range(slot, total)
+                    inputs.record_stream(compute)     # allocated on the copy stream, read on
+                    uploaded = torch.cuda.Event()     # the compute stream
                     uploaded.record(copies)
+                address = inputs.data_ptr()
+                members = []
+                for offsets, nodes, edges, records, kept in packed:
+                    members.append(engine.pointer_shard(
+                        [address + offset if offset >= 0 else 0 for offset in offsets],
+                        nodes=nodes, edges=edges, records=records,
+                        out=block[first:first + kept], keep=inputs))
+                    first += kept
                 compute.wait_event(uploaded)
-                engine.encode_coo_group(members)
+                engine.encode_coo_group_pointers(members)
         except BaseException:
-            _settle(jobs)
+            _settle([job for _slot, _total, jobs_of in submitted for job in jobs_of])
             raise
         return block, counts
 

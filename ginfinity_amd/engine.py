@@ -402,6 +402,48 @@ class DeviceEncoder:
                 scratch.numel(), stream.cuda_stream), "gfy_encode_coo_batch")
             self._coo_enqueued(rows, stream)
 
+    # -- the same from device ADDRESSES (no tensor per array: encode_shards_device) -------------
+    @staticmethod
+    def pointer_shard(pointers, *, nodes: int, edges: int, records: int, out: torch.Tensor,
+                      keep=None) -> tuple:
+        """One micro-batch for ``encode_coo_group_pointers``: ``pointers`` = device addresses of
+        (node_features f32 [nodes][7], edge_index i32 [2][edges], edge_types u8 [edges], out_rows
+        i32 [nodes] or 0, node_ptr i64 [records + 1] or 0, edge_ptr or 0) — one upload block cut
+        by offsets (``api._Uploader.send_block``); ``keep``: what owns that memory."""
+        assert out.is_contiguous() and out.shape[1] == EMBEDDING_DIM
+        return (tuple(pointers), nodes, edges, records, out, keep)
+
+    def encode_coo_group_pointers(self, members, *, normalise: bool = True) -> None:
+        """``encode_coo_group`` for micro-batches described by addresses (``pointer_shard``)."""
+        if not 1 <= len(members) <= native.GFY_MAX_BATCH_SHARDS:
+            raise ValueError(f"a batch holds 1..{native.GFY_MAX_BATCH_SHARDS} shards, "
+                             f"got {len(members)}")
+        count = len(members)
+        array = (native.GfyShard * count)()
+        rows = 0
+        for slot, (pointers, nodes, edges, records, out, _keep) in zip(array, members):
+            p_x, p_ei, p_et, p_rows, p_np, p_ep = pointers
+            slot.node_features, slot.out = p_x, out.data_ptr()
+            slot.edge_index = p_ei if edges else None
+            slot.edge_types = p_et if edges else None
+            slot.out_rows = p_rows or None
+            slot.n_nodes, slot.n_edges = nodes, edges
+            if records > 0 and p_np and p_ep and edges:
+                slot.node_ptr, slot.edge_ptr, slot.n_records = p_np, p_ep, records
+            rows += -(-nodes // 32) * 32
+        out_code = _GFY_OF_TORCH[members[0][4].dtype]
+        lib = self._lib
+        with torch.cuda.device(self.device):
+            need = lib.gfy_encode_coo_batch_workspace_bytes(self._handle, array, count)
+            if need == 0:
+                native.check(native.GFY_ERR_INVALID, "gfy_encode_coo_batch_workspace_bytes")
+            stream = torch.cuda.current_stream(self.device)
+            scratch = self._coo_scratch(need, rows, stream)
+            native.check(lib.gfy_encode_coo_batch(
+                self._handle, array, count, out_code, 1 if normalise else 0, _ptr(scratch),
+                scratch.numel(), stream.cuda_stream), "gfy_encode_coo_batch")
+            self._coo_enqueued(rows, stream)
+
     def hidden(self, node_features: torch.Tensor, csr: DeviceCsr,
                stage: int) -> torch.Tensor:
         """Parity tap: hidden state after ``stage`` (0 = input Linear,
