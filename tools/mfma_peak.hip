@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void k_mfma16(float* out, int iters, unsigned 
   for (int i = 0; i < iters; ++i) {
 #pragma unroll
     for (int c = 0; c < 4 * kChains; ++c)   // 4 x (16x16x32) = the MACs of one 32x32x16... x2: see flop below
-      acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[c], 0, 0, 0);
+      asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[c]) : "v"(a), "v"(b));   // in place: the
+      // builtin's accumulators were allocated as a rotating, overlapping register window
   }
   const unsigned long long c1 = clock64();
   const unsigned long long t1 = __builtin_readcyclecounter();
