@@ -719,6 +719,7 @@ static int batch_table(const gfy_shard* shards, int count, const char* who, Shar
     RecordTable r{};
     bool all = true;
     int ranges = 0;
+    r.range_rows = t.total_rows() <= kRecSmallBatchRows ? kRecRowsSmall : kRecRowsLarge;
     for (int s = 0; s < count; ++s) {
       const gfy_shard& one = shards[s];
       const bool given = one.node_ptr && one.edge_ptr && one.n_records > 0;
@@ -732,7 +733,7 @@ static int batch_table(const gfy_shard* shards, int count, const char* who, Shar
       r.edge_ptr[s] = one.edge_ptr;
       r.records[s] = (int)one.n_records;
       r.range_base[s] = ranges;
-      ranges += (int)((one.n_nodes + kRecRows - 1) / kRecRows);
+      ranges += (int)((one.n_nodes + r.range_rows - 1) / r.range_rows);
     }
     r.range_base[count] = ranges;
     *records = r;

@@ -522,9 +522,14 @@ static int encode_f16_on(const gfy_encoder* enc, const ShardTable& shards, const
 #else
       const int ranges = coo->records->range_base[shards.shards], linear = linear_blocks;
 #endif
-      k_encode_setup_rec<<<ranges + linear, 256, 0, s>>>(
-          shards, *coo->records, enc->f16.w_in, enc->f16.b_in, ha, coo->row_ptr, coo->col,
-          coo->typ, coo->scratch.perm, plans, ranges, enc->edge_dim);
+      if (coo->records->range_rows == kRecRowsLarge)
+        k_encode_setup_rec<kRecRowsLarge><<<ranges + linear, 256, 0, s>>>(
+            shards, *coo->records, enc->f16.w_in, enc->f16.b_in, ha, coo->row_ptr, coo->col,
+            coo->typ, coo->scratch.perm, plans, ranges, enc->edge_dim);
+      else
+        k_encode_setup_rec<kRecRowsSmall><<<ranges + linear, 256, 0, s>>>(
+            shards, *coo->records, enc->f16.w_in, enc->f16.b_in, ha, coo->row_ptr, coo->col,
+            coo->typ, coo->scratch.perm, plans, ranges, enc->edge_dim);
     }
     else if (coo && coo->scan_free)   // + last CSR stage (row offsets included) + tile plans
       k_encode_setup_coo<false><<<layer_tiles + linear_blocks, 256, 0, s>>>(

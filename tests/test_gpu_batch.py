@@ -288,6 +288,27 @@ def test_record_boundaries_change_nothing_but_the_launches(gpu_encoder, mixed_sh
         engine.set_option(native.GFY_OPT_LAYER_KERNEL, -1)
 
 
+def test_record_ranges_of_both_sizes_give_the_counting_path_bytes(gpu_encoder):
+    """The range workgroups own 256 rows in a batch of up to 150,000 rows and 768 above
+    (gfy_common.h: kRecRowsSmall / kRecRowsLarge): the same shards alone (small ranges) and
+    in one batch of 263,500 rows (large ranges; direct-path tiles and hub rows inside them, a
+    shard whose last range is ragged, shard bases that are no multiple of 768) give the bytes of
+    the counting path."""
+    engine = gpu_encoder._engine
+    shards = [synthetic.roofline_shard(0), synthetic.roofline_shard(1),
+              synthetic.arbitrary_shard(3, nodes=20_000, edges=90_000, records=5, hub_degree=60),
+              synthetic.roofline_shard(2, records=7, length=500),
+              synthetic.roofline_shard(4)]
+    assert sum(s.node_count for s in shards) > 150_000
+    alone = [engine.encode_coo_batch([_device(engine, s)])[0].cpu().numpy() for s in shards]
+    for group in ([[s] for s in shards] + [shards, shards[2:], shards[::-1]]):
+        ranged = [o.cpu().numpy() for o in
+                  engine.encode_coo_batch([_device_with_records(engine, s) for s in group])]
+        for got, shard in zip(ranged, group):
+            want = alone[next(i for i, s in enumerate(shards) if s is shard)]
+            assert got.tobytes() == want.tobytes(), (len(group), shard.node_count)
+
+
 def test_record_boundaries_and_counting_calls_share_one_workspace(gpu_encoder):
     """A call with record boundaries leaves the counting scratch untouched (zero), so calls of
     both kinds may alternate on one encoder workspace (encode_coo_group)."""
