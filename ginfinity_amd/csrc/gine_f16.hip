@@ -518,7 +518,8 @@ static int encode_f16_on(const gfy_encoder* enc, const ShardTable& shards, const
 #ifdef GFY_DIAG_SETUP_SPLIT   // diagnostic: GFY_DIAG_SETUP=1 range workgroups only, 2 Linear only (wrong results)
       static const int diag = getenv("GFY_DIAG_SETUP") ? atoi(getenv("GFY_DIAG_SETUP")) : 0;
       const int ranges = diag == 2 ? 0 : coo->records->range_base[shards.shards];
-      const int linear = diag == 1 ? 0 : linear_blocks;
+      static const int diag_linear = getenv("GFY_DIAG_LINEAR") ? atoi(getenv("GFY_DIAG_LINEAR")) : 0;
+      const int linear = diag == 1 ? 0 : diag_linear > 0 ? diag_linear : linear_blocks;
 #else
       const int ranges = coo->records->range_base[shards.shards], linear = linear_blocks;
 #endif
