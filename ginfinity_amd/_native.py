@@ -8,9 +8,15 @@ from __future__ import annotations
 import ctypes
 from ctypes import (POINTER, Structure, c_char_p, c_int, c_int32, c_int64, c_size_t,
                     c_uint32, c_void_p)
+import os
 from pathlib import Path
 
-LIBRARY_PATH = Path(__file__).resolve().parent / "csrc" / "libgfy.so"
+#: the in-tree build (python -m ginfinity_amd.build).  The library is opened BY THIS PATH:
+#: LD_LIBRARY_PATH does not redirect it.  GFY_LIBRARY names another build of the same sources for
+#: a side-by-side measurement (tools/: a diagnostic build next to the default one); it must pass
+#: the same ABI and symbol checks.
+LIBRARY_PATH = Path(os.environ.get("GFY_LIBRARY") or
+                    Path(__file__).resolve().parent / "csrc" / "libgfy.so")
 #: gine_host.cpp + gfy_base.cpp built with the host compiler: no HIP runtime behind it
 HOST_LIBRARY_PATH = Path(__file__).resolve().parent / "csrc" / "libgfy_host.so"
 

@@ -234,3 +234,31 @@ def test_cpu_device_error_text_survives_the_gpu_library():
     done = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True,
                           timeout=300)
     assert done.returncode == 0 and done.stdout.strip() == "ok", done.stderr[-2000:]
+
+
+def test_gfy_library_names_the_build_that_is_opened(tmp_path):
+    """The GPU library is opened by its path (LD_LIBRARY_PATH does not redirect it); GFY_LIBRARY
+    names another build for a side-by-side measurement, and a path that is not there fails loudly
+    instead of falling back to the in-tree build."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    in_tree = root / "ginfinity_amd" / "csrc" / "libgfy.so"
+    copy = tmp_path / "libgfy_copy.so"
+    shutil.copy(in_tree, copy)
+    script = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from ginfinity_amd import _native as native\n"
+        "lib = native.library()\n"
+        "maps = open('/proc/self/maps').read()\n"
+        "print(native.LIBRARY_PATH, 'libgfy_copy.so' in maps, 'csrc/libgfy.so' in maps)\n" % str(root))
+    done = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True,
+                          timeout=300, env={**os.environ, "GFY_LIBRARY": str(copy)})
+    assert done.returncode == 0, done.stderr[-2000:]
+    assert done.stdout.split() == [str(copy), "True", "False"]
+    missing = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True,
+                             timeout=300, env={**os.environ, "GFY_LIBRARY": str(tmp_path / "nope.so")})
+    assert missing.returncode != 0 and "nope.so is missing" in missing.stderr
