@@ -121,6 +121,10 @@ def _advise_huge_pages(block: np.ndarray) -> None:
 MICROBATCH_GROUP = 4
 
 
+#: groups of micro-batches ``encode_staged`` keeps in flight (2: as ``bench.py --streams 2``)
+STAGED_LANES = 2
+
+
 def _groups(count: int, size: int | None = None, *, ramp: bool = False) -> list[range]:
     """Consecutive micro-batches per launch sequence.  ``ramp``: the first groups hold 1, 1, 2
     micro-batches — a call that returns host arrays is bound by the copy engine (230 MB at
@@ -471,6 +475,7 @@ class Ginfinity:
         self._preparer: ThreadPoolExecutor | None = None
         self._uploader: _Uploader | None = None
         self._copy_stream: "torch.cuda.Stream | None" = None
+        self._lanes: "list[tuple[DeviceEncoder, torch.cuda.Stream]] | None" = None
         self._metadata = checkpoint.metadata
         self._state = checkpoint.state
         self._config = checkpoint.config
@@ -949,16 +954,50 @@ class Ginfinity:
         if (tuple(block.shape) != (rows, self.embedding_dimension)
                 or block.dtype != torch.float16 or not block.is_contiguous()):
             raise ValueError("out must be a contiguous float16 [total core rows, 128] tensor")
+        groups = _groups(len(staged))
+        # Two groups in flight (fp16 model): the tail of one group's layer launches — the last,
+        # partial round of tiles — runs under the next group's workgroups.  Each lane is an
+        # encoder of its own (hidden-state buffers, workspace) on a stream of its own; the
+        # caller's stream waits for both.  ``STAGED_LANES = 1``: one group after the other.
+        lanes = self._two_lanes() if (STAGED_LANES > 1 and len(groups) > 1
+                                      and not self.full_precision) else None
+        current = torch.cuda.current_stream(self._engine.device)
+        if lanes:
+            ready = torch.cuda.Event()
+            ready.record(current)                 # the staged arrays, `out`'s previous readers
+            for _engine, stream in lanes:
+                stream.wait_event(ready)
         first = 0
-        for group in _groups(len(staged)):
+        for number, group in enumerate(groups):
             members = []
             for index in group:
                 features, edge_index, edge_types, out_rows, kept = staged[index]
                 members.append((features, edge_index, edge_types, out_rows,
                                 block[first:first + kept]))
                 first += kept
-            self._engine.encode_coo_group(members)
+            if lanes:
+                engine, stream = lanes[number % len(lanes)]
+                with torch.cuda.stream(stream):
+                    engine.encode_coo_group(members)
+            else:
+                self._engine.encode_coo_group(members)
+        if lanes:
+            for _engine, stream in lanes:
+                done = torch.cuda.Event()
+                done.record(stream)
+                current.wait_event(done)
         return block
+
+    def _two_lanes(self) -> "list[tuple[DeviceEncoder, torch.cuda.Stream]]":
+        if self._lanes is None:
+            device = self._engine.device
+            self._lanes = [(self._engine, torch.cuda.Stream(device=device)),
+                           (self._engine.twin(), torch.cuda.Stream(device=device))]
+        twin = self._lanes[1][0]
+        for option, value in self._engine._options.items():   # switches set since the twin was made
+            if twin._options.get(option) != value:
+                twin.set_option(option, value)
+        return self._lanes
 
     def encode_shards_device(self, shards: Sequence[GraphShard], *,
                              max_batch_nodes: int = 60_000, max_batch_edges: int = 300_000,

@@ -99,6 +99,8 @@ class DeviceEncoder:
                 native.GFY_F32 if full_precision else native.GFY_F16,
                 index, ctypes.byref(handle)), "gfy_encoder_create")
         self._handle = handle
+        self._weight_pack = weight_pack            # a second lane's encoder is made from it (twin)
+        self._options: dict[int, int] = {}
         self._workspace: torch.Tensor | None = None
         # gfy_encode_coo's own workspace: its leading counters are zero between calls as long
         # as nobody else writes to it (include/gfy.h), so it is never shared with _scratch
@@ -486,6 +488,18 @@ class DeviceEncoder:
         last layer launch or not."""
         native.check(self._lib.gfy_encoder_set_option(
             self._handle, int(option), int(value)), "gfy_encoder_set_option")
+        self._options[int(option)] = int(value)
+
+    def twin(self) -> "DeviceEncoder":
+        """A second gfy_encoder of the same weights on the same device, with this one's
+        options: a call in flight owns its encoder's hidden-state buffers and workspace, so two
+        groups of micro-batches in flight (``Ginfinity.encode_staged``: what ``bench.py`` times)
+        need two."""
+        other = DeviceEncoder(self._weight_pack, full_precision=self.full_precision,
+                              device=self.device)
+        for option, value in self._options.items():
+            other.set_option(option, value)
+        return other
 
     def last_layer_kernel(self) -> int:
         """Layer kernel of the last fp16-model encode (``native.GFY_OPT_LAYER_KERNEL`` values:

@@ -239,6 +239,41 @@ def test_records_and_device_blocks_take_the_grouped_path_too(gpu_encoder, rouski
     assert counts == shard.core_counts and list(map(len, many)) == [700, 800]
 
 
+def test_staged_groups_in_two_lanes_give_the_one_lane_bytes(gpu_encoder, rouskin_shard, monkeypatch):
+    """``encode_staged`` keeps two groups of micro-batches in flight (two encoders, two streams:
+    what ``bench.py`` times).  Same bytes as one group after the other, call after call into the
+    same block, with ragged last groups, with a layer-kernel switch set after the second lane's
+    encoder exists, and with work of the caller's stream in front of and behind the call."""
+    from ginfinity_amd import api, _native as native
+    shards = [rouskin_shard, synthetic.roofline_shard(5), synthetic.arbitrary_shard(9)]
+    staged, counts = gpu_encoder.stage_shards(shards)
+    assert len(staged) >= 15 and [len(c) for c in counts] == [s.record_count for s in shards]
+    monkeypatch.setattr(api, "STAGED_LANES", 1)
+    want = gpu_encoder.encode_staged(staged).cpu().numpy()
+    monkeypatch.setattr(api, "STAGED_LANES", 2)
+    block = torch.full(want.shape, float("nan"), dtype=torch.float16, device=gpu_encoder._engine.device)
+    for _ in range(3):
+        block.fill_(float("nan"))                       # on the caller's stream, in front of the call
+        got = gpu_encoder.encode_staged(staged, out=block)
+        total = got.float().sum()                       # ... and behind it
+        assert got.cpu().numpy().tobytes() == want.tobytes()
+        assert bool(torch.isfinite(total))
+    assert gpu_encoder._lanes is not None and len(gpu_encoder._lanes) == 2
+    for size in (3, 2):                                  # ragged groups, more of them
+        monkeypatch.setattr(api, "MICROBATCH_GROUP", size)
+        assert gpu_encoder.encode_staged(staged).cpu().numpy().tobytes() == want.tobytes()
+    monkeypatch.setattr(api, "MICROBATCH_GROUP", 4)
+    try:
+        gpu_encoder._engine.set_option(native.GFY_OPT_LAYER_KERNEL, 3)
+        assert gpu_encoder.encode_staged(staged).cpu().numpy().tobytes() == want.tobytes()
+        assert [e.last_layer_kernel() for e, _stream in gpu_encoder._lanes] == [3, 3]
+    finally:
+        gpu_encoder._engine.set_option(native.GFY_OPT_LAYER_KERNEL, -1)
+    # the encoder's other paths still work behind a two-lane call (its workspace changed streams)
+    assert np.concatenate(gpu_encoder.encode_graphs(shards[1])).tobytes() == \
+        want[sum(map(sum, counts[:1])):sum(map(sum, counts[:2]))].tobytes()
+
+
 def _device_with_records(engine, shard):
     """As ``_device``, with the shard's record boundaries riding on the edge_index tensor (what
     ``Ginfinity.stage_shards`` uploads): the batch call then takes the record-range set-up."""
