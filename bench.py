@@ -318,7 +318,8 @@ def cross_shard(args, rank: int, local_rank: int, world: int, distributed: bool,
         dist.all_reduce(worst, op=dist.ReduceOp.MAX)
         return float(worst.item())
 
-    # Encode leg: this rank's shards, their micro-batches in groups of four per launch sequence
+    # Encode leg: this rank's shards, their micro-batches in groups of four per launch sequence,
+    # two groups in flight
     # (Ginfinity.encode_staged = gfy_encode_coo_batch).  The shards are staged on the device
     # first and that upload is timed by itself: `encode` is the hot path with its inputs
     # resident in HBM, `stage` the PCIe-bound feeding of it.  A rank without
@@ -373,7 +374,7 @@ def cross_shard(args, rank: int, local_rank: int, world: int, distributed: bool,
                        "rccl_ranks": dist.get_world_size() if distributed else 0},
             "encode": {"seconds": encode_s, "nodes_per_s": total / encode_s,
                        "note": "inputs resident on the device, embeddings left there; the "
-                               "micro-batches in groups of 4 per launch sequence"},
+                               "micro-batches in groups of 4 per launch sequence, two groups in flight"},
             "stage": {"seconds": stage_s,
                       "note": "numpy shards -> device arrays of the owned shards (PCIe, pageable, "
                               "synchronous)"},
