@@ -529,6 +529,22 @@ PairWorkspace carve(void* base, int64_t n, int64_t m) {
   w.blocks_a = (int)((n + kBlockA - 1) / kBlockA);
   const int64_t tiles_b = (m + kTileB - 1) / kTileB;
   int64_t chunks = (1024 + w.blocks_a - 1) / w.blocks_a;
+  {
+    // One workgroup per CU at a time, all of one length: a grid of blocks_a x chunks workgroups
+    // ends after ceil(grid / CUs) of them, each 1 / chunks of a sweep long.  1,000,000 rows are
+    // 3,907 a-blocks = 15.26 per CU: one chunk ends after 16 sweeps, three after 46 / 3 = 15.33.
+    // A few more chunks than the minimum cost a merge entry per a-row and chunk (k_nearest_finish).
+    constexpr int64_t kCus = 256;   // MI355X; another part only loses the fit
+    const int64_t least = chunks;
+    double best = 1e300;
+    for (int64_t c = least; c < least + 6; ++c) {
+      const double sweeps = (double)((w.blocks_a * c + kCus - 1) / kCus) / (double)c;
+      if (sweeps < best * 0.99) best = sweeps, chunks = c;   // a later count only for a real gain
+    }
+  }
+#ifdef GFY_DIAG_PAIRWISE_CHUNKS   // diagnostic builds: the sweep behind the choice above (profiles/README.md)
+  if (const char* forced = getenv("GFY_PAIRWISE_CHUNKS")) chunks = atoll(forced);
+#endif
   if (chunks > tiles_b) chunks = tiles_b;
   if (chunks < 1) chunks = 1;
   const int64_t tiles_per_chunk = (tiles_b + chunks - 1) / chunks;
