@@ -223,13 +223,14 @@ struct ShardTable {
 // list).  With them the COO -> plans stage needs no global atomics (csr_records.inc): a
 // workgroup owns kRecRows consecutive rows of one shard and scans only the edges of the records
 // that overlap them.  `range_base`: workgroups of that stage, per shard; `range_rows`: rows per
-// workgroup, kRecRowsSmall for a batch of up to kRecSmallBatchRows rows (a lone 60,000-node
+// workgroup, kRecRowsSmall for a batch of up to kRecSmallBatchRows rows (three 60,000-node
+// micro-batches and fewer; a lone 60,000-node
 // micro-batch: 235 workgroups, every one resident at once, and a workgroup's latency chain is the
 // launch — 512 / 768 rows cost it 4 / 10 us), kRecRowsLarge above (four shards: the scan of a
 // workgroup covers its records once for three times the rows, and fewer workgroups stand in the
 // way of the input Linear's: 41.7 -> 37.2 us; 512 rows 37.9, 1,024 rows 41.5).
 constexpr int kRecRowsSmall = 256, kRecRowsLarge = 768;
-constexpr int64_t kRecSmallBatchRows = 150000;
+constexpr int64_t kRecSmallBatchRows = 200000;   // 180,000 rows: 220.3 (256) against 222.0 us (768) per call; 210,000: 253 / 252; 240,000: 278 / 276
 struct RecordTable {
   const int64_t* node_ptr[kMaxBatchShards];   // [records + 1], shard-local, ascending
   const int64_t* edge_ptr[kMaxBatchShards];   // [records + 1]

@@ -324,9 +324,9 @@ def test_record_boundaries_change_nothing_but_the_launches(gpu_encoder, mixed_sh
 
 
 def test_record_ranges_of_both_sizes_give_the_counting_path_bytes(gpu_encoder):
-    """The range workgroups own 256 rows in a batch of up to 150,000 rows and 768 above
+    """The range workgroups own 256 rows in a batch of up to 200,000 rows and 768 above
     (gfy_common.h: kRecRowsSmall / kRecRowsLarge): the same shards alone (small ranges) and
-    in one batch of 263,500 rows (large ranges; direct-path tiles and hub rows inside them, a
+    in one batch of 203,500 rows (large ranges; direct-path tiles and hub rows inside them, a
     shard whose last range is ragged, shard bases that are no multiple of 768) give the bytes of
     the counting path."""
     engine = gpu_encoder._engine
@@ -334,7 +334,7 @@ def test_record_ranges_of_both_sizes_give_the_counting_path_bytes(gpu_encoder):
               synthetic.arbitrary_shard(3, nodes=20_000, edges=90_000, records=5, hub_degree=60),
               synthetic.roofline_shard(2, records=7, length=500),
               synthetic.roofline_shard(4)]
-    assert sum(s.node_count for s in shards) > 150_000
+    assert sum(s.node_count for s in shards) > 200_000
     alone = [engine.encode_coo_batch([_device(engine, s)])[0].cpu().numpy() for s in shards]
     for group in ([[s] for s in shards] + [shards, shards[2:], shards[::-1]]):
         ranged = [o.cpu().numpy() for o in
