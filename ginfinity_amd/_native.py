@@ -45,6 +45,9 @@ SIGNATURES: dict[str, tuple] = {
     "gfy_last_error": (c_char_p, []),
     "gfy_abi_version": (c_int, []),
     "gfy_weight_pack_bytes": (c_size_t, [c_uint32] * 5),
+    "gfy_pack_microbatch": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p,
+                                    c_int64, POINTER(c_int64), POINTER(c_int64)]),
     "gfy_encoder_create": (c_int, [c_void_p, c_size_t, c_int, c_int,
                                    POINTER(c_void_p)]),
     "gfy_encoder_destroy": (None, [c_void_p]),
@@ -95,7 +98,7 @@ SIGNATURES: dict[str, tuple] = {
 
 
 #: what device="cpu" calls (a subset of SIGNATURES; libgfy.so exports them too)
-HOST_SYMBOLS = ("gfy_last_error", "gfy_abi_version", "gfy_weight_pack_bytes",
+HOST_SYMBOLS = ("gfy_last_error", "gfy_abi_version", "gfy_weight_pack_bytes", "gfy_pack_microbatch",
                 "gfy_host_encoder_create", "gfy_host_encoder_destroy", "gfy_host_encode")
 
 

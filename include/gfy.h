@@ -305,6 +305,28 @@ int gfy_host_encode(const gfy_host_encoder* encoder, const float* node_features,
                     int64_t n_edges, const int32_t* out_rows, void* out, int out_dtype,
                     int normalise, int threads);
 
+/* ---- host-side packing of one micro-batch (no HIP call; exported by both libraries) ------
+ * Records [start, stop) of a host shard -> one staging block, laid out as the device arrays of a
+ * gfy_shard: what Ginfinity.encode_graphs does per micro-batch with GraphShard.slice
+ * (api.py:211-230, graph.py:414-444: node rows cut, edge_index rebased by -node_ptr[start],
+ * ptr arrays cut) plus the core-row map of api.py:253-257 — in ONE call that holds no
+ * interpreter lock, so a pool of packer threads scales (the numpy form of it kept the packers of
+ * 128 micro-batches behind one lock: 19-24 ms for 561 MB).
+ *   slot + base      where the block starts (page-locked staging memory; base % 256 == 0)
+ *   offsets[6]       out: byte offsets FROM `slot` of node_features, edge_index (2 x edges),
+ *                    edge_types, out_rows (int32, -1 = dropped row; absent when every node is a
+ *                    core node), node_ptr, edge_ptr (absent unless with_records and every
+ *                    record has <= 65,536 edges); -1 = absent; every array starts at a multiple
+ *                    of 256
+ *   counts[4]        out: nodes, edges, records (0 = boundaries absent), kept rows
+ * Returns GFY_ERR_INVALID (gfy_last_error: which) for an edge that leaves the records' node range
+ * — the check of GraphShard.slice (graph.py:318-321).                                          */
+int gfy_pack_microbatch(const float* node_features, int feature_dim, const int32_t* edge_index,
+                        int64_t edges_total, const uint8_t* edge_types,
+                        const uint8_t* node_roles, const int64_t* node_ptr,
+                        const int64_t* edge_ptr, int64_t start, int64_t stop, int with_records,
+                        void* slot, int64_t base, int64_t* offsets, int64_t* counts);
+
 /* ---- all-pairs distance over 128-d embeddings ----------------------------------
  * No reference symbol (the aligner lives in the external `ginfinity-sw`;
  * only parameters are exported: api.py:47-50, data/alignment.json:6) — defined

@@ -467,3 +467,53 @@ def test_record_boundaries_ride_on_the_edge_index_tensor():
     # the descriptor the C ABI takes has the three optional fields at its end (ABI 4)
     names = [name for name, _kind in native.GfyShard._fields_]
     assert names[-3:] == ["node_ptr", "edge_ptr", "n_records"] and native.ABI_VERSION == 4
+
+
+def test_native_packer_writes_the_bytes_of_the_numpy_packer():
+    """``gfy_pack_microbatch`` (csrc/gfy_base.cpp: one call without the interpreter lock) against
+    ``_pack_microbatch_at`` + ``_Uploader.pack_at`` in numpy: the same offsets, counts and staging
+    bytes — whole shards and record ranges in the middle (edge_index rebased), context rows
+    (``out_rows``), a record too long for record boundaries, one-record and one-node ranges — and
+    the reference's error for an edge that leaves the records' node range (graph.py:318-321)."""
+    import torch
+    from ginfinity_amd import api, synthetic
+    from ginfinity_amd.spec import GraphValidationError
+
+    class Slots(api._Uploader):
+        def __init__(self):
+            self._staging = [torch.zeros(12 << 20, dtype=torch.uint8) for _ in range(2)]
+
+    long_record = synthetic.roofline_shard(3, records=1, length=16_000)   # 80,000 edges in one record
+    cases = [(synthetic.roofline_shard(1, records=5, length=600), [(0, 5), (1, 4), (2, 3), (4, 5)]),
+             (synthetic.arbitrary_shard(2, nodes=5000, edges=20000, records=6), [(0, 6), (1, 5), (3, 4)]),
+             (synthetic.arbitrary_shard(7, nodes=40, edges=90, records=4, hub_degree=3), [(0, 4), (2, 3)]),
+             (long_record, [(0, 1)])]
+    slots = Slots()
+    for shard, ranges in cases:
+        assert api._packable(shard)
+        for start, stop in ranges:
+            for base in (0, 4096):
+                got, want = [], []
+                for native_packer, slot, sink in ((True, 0, got), (False, 1, want)):
+                    api.NATIVE_PACKER = native_packer
+                    slots._staging[slot].zero_()
+                    try:
+                        sink.append(api.Ginfinity._pack_microbatch_at(slots, slot, base, shard, start, stop))
+                    finally:
+                        api.NATIVE_PACKER = True
+                (offsets_a, *counts_a), (offsets_b, *counts_b) = got[0], want[0]
+                assert list(offsets_a) == list(offsets_b) and counts_a == counts_b, (start, stop)
+                assert api.Ginfinity._microbatch_bytes(shard, start, stop) >= max(offsets_a) - base
+                assert slots._staging[0].numpy().tobytes() == slots._staging[1].numpy().tobytes()
+    assert got[0][3] == 0                              # the 80,000-edge record travels without boundaries
+    broken = synthetic.roofline_shard(1, records=3, length=100)
+    edges = broken.edge_index.copy()
+    edges[0, 5] = 250                                   # record 0's edge points into record 2
+    object.__setattr__(broken, "edge_index", edges)
+    for native_packer in (True, False):
+        api.NATIVE_PACKER = native_packer
+        try:
+            with pytest.raises(GraphValidationError, match="edge index outside"):
+                api.Ginfinity._pack_microbatch_at(slots, 0, 0, broken, 0, 1)
+        finally:
+            api.NATIVE_PACKER = True
