@@ -48,6 +48,11 @@ SIGNATURES: dict[str, tuple] = {
     "gfy_pack_microbatch": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p,
                                     c_int64, POINTER(c_int64), POINTER(c_int64)]),
+    "gfy_upload_ring_create": (c_int, [c_int, POINTER(c_void_p)]),
+    "gfy_upload_ring_destroy": (None, [c_void_p]),
+    "gfy_upload_async": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p,
+                                 c_void_p]),
+    "gfy_upload_wait": (c_int, [c_void_p, c_int]),
     "gfy_encoder_create": (c_int, [c_void_p, c_size_t, c_int, c_int,
                                    POINTER(c_void_p)]),
     "gfy_encoder_destroy": (None, [c_void_p]),

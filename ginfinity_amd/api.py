@@ -140,6 +140,10 @@ def _packable(shard: GraphShard) -> bool:
 
 #: groups of micro-batches ``encode_staged`` keeps in flight (2: as ``bench.py --streams 2``)
 STAGED_LANES = 2
+#: ... and ``encode_shards_device`` (host arrays in): 1 — the call is bound by the uploads, a
+#: second lane costs 2–4 % there (128 shards: 12.8–13.0 against 13.1–13.7 ms on one box,
+#: tools/bench_host_feed.py --lanes)
+HOST_FEED_LANES = 1
 
 
 def _groups(count: int, size: int | None = None, *, ramp: bool = False) -> list[range]:
@@ -346,6 +350,14 @@ class _Uploader:
         self._copied: list["torch.cuda.Event | None"] = [None] * slots
         self._next = 0
         self.slots = slots
+        self._ring: int | None = None        # gfy_upload_ring (send_group), made on first use
+
+    def __del__(self) -> None:              # pragma: no cover - interpreter teardown order
+        try:
+            if self._ring:
+                native.library().gfy_upload_ring_destroy(self._ring)
+        except Exception:
+            pass
 
     def reserve(self) -> int:
         """Next staging slot (called by the launching thread, in micro-batch order)."""
@@ -428,6 +440,8 @@ class _Uploader:
         left it and its staging buffer holds ``total`` bytes."""
         if self._copied[slot] is not None:
             self._copied[slot].synchronize()
+        if self._ring:
+            native.check(native.library().gfy_upload_wait(self._ring, slot), "gfy_upload_wait")
         staging = self._staging[slot]
         if staging is None or staging.numel() < total:
             self._staging[slot] = torch.empty(max(total, 1 << 20), dtype=torch.uint8,
@@ -467,6 +481,27 @@ class _Uploader:
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(self._device))
         self._copied[slot] = done
+        return block
+
+    def send_group(self, slot: int, total: int, copies: "torch.cuda.Stream",
+                   consumer: "torch.cuda.Stream") -> torch.Tensor:
+        """``send_range`` on ``copies`` with ``consumer`` made to wait for it, in ONE native call
+        (``gfy_upload_async``: copy, event, stream wait): per group that was a ``copy_`` (89 us
+        of the calling thread), two event records, an event wait and a stream switch."""
+        lib = native.library()
+        if self._ring is None:
+            ring = ctypes.c_void_p()
+            with torch.cuda.device(self._device):
+                native.check(lib.gfy_upload_ring_create(self.slots, ctypes.byref(ring)),
+                             "gfy_upload_ring_create")
+            self._ring = ring.value
+        with torch.cuda.stream(copies):           # the block belongs to the copy stream's pool
+            block = torch.empty(max(total, 1), dtype=torch.uint8, device=self._device)
+        block.record_stream(consumer)
+        native.check(lib.gfy_upload_async(self._ring, slot, block.data_ptr(),
+                                          self._staging[slot].data_ptr(), total,
+                                          copies.cuda_stream, consumer.cuda_stream),
+                     "gfy_upload_async")
         return block
 
     def hold(self, packed, event: "torch.cuda.Event") -> None:
@@ -690,11 +725,27 @@ class Ginfinity:
                 "this encoder")
         if max_batch_nodes <= 0 or max_batch_edges <= 0:
             raise ValueError("batch node and edge limits must be positive")
-        if int(np.diff(shard.node_ptr).max()) > max_batch_nodes:
+        # (a shard that fits a micro-batch as a whole has no record that does not: the per-record
+        # maxima are looked at only above that — 7 us per shard of a 128-shard call's prologue)
+        if (int(shard.node_ptr[-1]) > max_batch_nodes
+                and int(np.diff(shard.node_ptr).max()) > max_batch_nodes):
             raise ValueError("max_batch_nodes is smaller than the longest graph")
-        if int(np.diff(shard.edge_ptr).max()) > max_batch_edges:
+        if (int(shard.edge_ptr[-1]) > max_batch_edges
+                and int(np.diff(shard.edge_ptr).max()) > max_batch_edges):
             raise ValueError("max_batch_edges is smaller than the largest graph")
         return shard
+
+    @staticmethod
+    def _shard_bounds(shard: GraphShard, max_batch_nodes: int, max_batch_edges: int
+                      ) -> list[tuple[int, int]]:
+        """``microbatch_bounds`` of a shard; one that fits the limits as a whole is one
+        micro-batch without the running sums (what the greedy packing gives for it)."""
+        records = shard.record_count
+        if (records and int(shard.node_ptr[-1]) <= max_batch_nodes
+                and int(shard.edge_ptr[-1]) <= max_batch_edges):
+            return [(0, records)]
+        return microbatch_bounds(shard.lengths, shard.edge_counts, max_batch_nodes,
+                                 max_batch_edges)
 
     def encode_graphs(self, graphs: Sequence[Graph] | GraphShard, *,
                       max_batch_nodes: int = 60_000,
@@ -830,6 +881,12 @@ class Ginfinity:
         total += pad(n * 4)                                   # out_rows (used or not)
         total += 2 * pad((stop - start + 1) * 8)              # node_ptr, edge_ptr (used or not)
         return total
+
+    @classmethod
+    def _pack_items(cls, uploader: "_Uploader", slot: int, items) -> list:
+        """Packer thread: ``_pack_microbatch_at`` for ``(base, shard, start, stop)`` items of one slot."""
+        return [cls._pack_microbatch_at(uploader, slot, base, shard, start, stop)
+                for base, shard, start, stop in items]
 
     @staticmethod
     def _pack_microbatch_at(uploader: "_Uploader", slot: int, base: int, shard: GraphShard,
@@ -1052,8 +1109,8 @@ class Ginfinity:
         for shard in shards:
             shard = self._checked_shard(shard, max_batch_nodes, max_batch_edges)
             counts.append(shard.core_counts)
-            plan += [(shard, a, b) for a, b in microbatch_bounds(
-                shard.lengths, shard.edge_counts, max_batch_nodes, max_batch_edges)]
+            plan += [(shard, a, b) for a, b in self._shard_bounds(
+                shard, max_batch_nodes, max_batch_edges)]
         rows = sum(sum(per_record) for per_record in counts)
         block = out
         if block is None:
@@ -1086,12 +1143,25 @@ class Ginfinity:
                 bases.append(at)
                 at += self._microbatch_bytes(shard, a, b)
             uploader.prepare_slot(slot, at)
-            for index, base in zip(group, bases):
-                shard, a, b = plan[index]
-                jobs_of.append(self._preparer.submit(self._pack_microbatch_at, uploader, slot, base,
-                                                     shard, a, b))
+            items = [(base, *plan[index]) for index, base in zip(group, bases)]
+            # the first groups: a packer per micro-batch (the copy engine is waiting for them);
+            # behind them a packer per GROUP — enough of them are packed ahead, and a job
+            # handed to the pool is 11 us of this thread
+            pieces = [[item] for item in items] if len(submitted) < 2 else [items]
+            for piece in pieces:
+                jobs_of.append(self._preparer.submit(self._pack_items, uploader, slot, piece))
             submitted.append((slot, at, jobs_of))
 
+        # ``HOST_FEED_LANES = 2``: two groups in flight as in ``encode_staged`` — a lane = an
+        # encoder and a stream of its own; group g runs on lane g mod 2 behind ITS upload only,
+        # the caller's stream waits for both at the end.  Not the default: see HOST_FEED_LANES.
+        lanes = self._two_lanes() if (HOST_FEED_LANES > 1 and len(groups) > 1
+                                      and not self.full_precision) else None
+        if lanes:
+            ready = torch.cuda.Event()
+            ready.record(compute)                 # `out`'s previous readers
+            for _engine, stream in lanes:
+                stream.wait_event(ready)
         first = 0
         ahead = max(1, uploader.slots - 1)   # groups packed ahead of the one being launched
         try:
@@ -1099,12 +1169,10 @@ class Ginfinity:
                 while len(submitted) < len(groups) and len(submitted) <= number + ahead - 1:
                     submit(groups[len(submitted)])
                 slot, total, jobs_of = submitted[number]
-                packed = [job.result() for job in jobs_of]
-                with torch.cuda.stream(copies):
-                    inputs = uploader.send_range(slot, total)
-                    inputs.record_stream(compute)     # allocated on the copy stream, read on
-                    uploaded = torch.cuda.Event()     # the compute stream
-                    uploaded.record(copies)
+                packed = [result for job in jobs_of for result in job.result()]
+                lane_engine, lane_stream = lanes[number % len(lanes)] if lanes else (engine, compute)
+                # one native call: H2D copy on the copy stream, the lane waits for it
+                inputs = uploader.send_group(slot, total, copies, lane_stream)
                 address = inputs.data_ptr()
                 members = []
                 for offsets, nodes, edges, records, kept in packed:
@@ -1113,11 +1181,17 @@ class Ginfinity:
                         nodes=nodes, edges=edges, records=records,
                         out=block[first:first + kept], keep=inputs))
                     first += kept
-                compute.wait_event(uploaded)
-                engine.encode_coo_group_pointers(members)
+                with torch.cuda.stream(lane_stream):
+                    lane_engine.encode_coo_group_pointers(members)
         except BaseException:
             _settle([job for _slot, _total, jobs_of in submitted for job in jobs_of])
             raise
+        finally:
+            if lanes:
+                for _engine, stream in lanes:
+                    done = torch.cuda.Event()
+                    done.record(stream)
+                    compute.wait_event(done)
         return block, counts
 
     def encode_graphs_device(self, shard: GraphShard, *,

@@ -122,6 +122,12 @@ struct Reader {
 
 using namespace gfy;
 
+struct gfy_upload_ring {     // include/gfy.h: one event per staging slot of the caller
+  int slots = 0;
+  hipEvent_t done[64] = {};
+  bool used[64] = {};
+};
+
 extern "C" {
 
 int gfy_encoder_create(const void* weight_pack_host, size_t bytes,
@@ -471,6 +477,57 @@ int gfy_encoder_set_option(gfy_encoder* enc, int option, int value) {
       set_error("gfy_encoder_set_option: unknown option %d", option);
       return GFY_ERR_INVALID;
   }
+}
+
+int gfy_upload_ring_create(int slots, gfy_upload_ring** ring_out) {
+  clear_error();
+  GFY_REQUIRE(ring_out && slots >= 1 && slots <= 64, GFY_ERR_INVALID,
+              "gfy_upload_ring_create: NULL argument or slots %d outside 1..64", slots);
+  gfy_upload_ring* ring = new gfy_upload_ring();
+  ring->slots = slots;
+  for (int slot = 0; slot < slots; ++slot) {
+    hipError_t err = hipEventCreateWithFlags(&ring->done[slot], hipEventDisableTiming);
+    if (err != hipSuccess) {
+      set_error("hipEventCreateWithFlags failed: %s", hipGetErrorString(err));
+      ring->slots = slot;
+      gfy_upload_ring_destroy(ring);
+      return GFY_ERR_HIP;
+    }
+  }
+  *ring_out = ring;
+  return GFY_OK;
+}
+
+void gfy_upload_ring_destroy(gfy_upload_ring* ring) {
+  if (!ring) return;
+  for (int slot = 0; slot < ring->slots; ++slot) (void)hipEventDestroy(ring->done[slot]);
+  delete ring;
+}
+
+int gfy_upload_async(gfy_upload_ring* ring, int slot, void* device_dst, const void* pinned_src,
+                     size_t bytes, void* copy_stream, void* consumer_stream) {
+  clear_error();
+  GFY_REQUIRE(ring && slot >= 0 && slot < ring->slots, GFY_ERR_INVALID,
+              "gfy_upload_async: NULL ring or slot %d outside its slots", slot);
+  GFY_REQUIRE(bytes == 0 || (device_dst && pinned_src), GFY_ERR_INVALID,
+              "gfy_upload_async: NULL source or destination");
+  hipStream_t copies = static_cast<hipStream_t>(copy_stream);
+  if (bytes)
+    GFY_CHECK_HIP(hipMemcpyAsync(device_dst, pinned_src, bytes, hipMemcpyHostToDevice, copies));
+  GFY_CHECK_HIP(hipEventRecord(ring->done[slot], copies));
+  ring->used[slot] = true;
+  if (consumer_stream != copy_stream)
+    GFY_CHECK_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(consumer_stream),
+                                     ring->done[slot], 0));
+  return GFY_OK;
+}
+
+int gfy_upload_wait(gfy_upload_ring* ring, int slot) {
+  clear_error();
+  GFY_REQUIRE(ring && slot >= 0 && slot < ring->slots, GFY_ERR_INVALID,
+              "gfy_upload_wait: NULL ring or slot %d outside its slots", slot);
+  if (ring->used[slot]) GFY_CHECK_HIP(hipEventSynchronize(ring->done[slot]));
+  return GFY_OK;
 }
 
 int gfy_encoder_last_layer_kernel(const gfy_encoder* enc) {

@@ -6,8 +6,12 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #include "../../include/gfy.h"
 
@@ -33,6 +37,75 @@ size_t pack_floats(uint32_t in_dim, uint32_t h, uint32_t layers, uint32_t edge_d
                            2 * h;
   return (size_t)h * in_dim + h + layers * per_layer + (size_t)h * h + h +
          (size_t)out_dim * h + out_dim;
+}
+
+// Copies into page-locked staging memory (gfy_pack_microbatch).  The destination is written
+// once and next read by the copy engine, never by this core: streaming stores leave it out of
+// the cache and spare the read-for-ownership of every destination line (a third of the copy's
+// memory traffic).  GFY_PACK_STREAM=0 keeps memcpy (A/B runs: tools/bench_host_feed.py).
+static bool stream_stores() {   // read per call (once per ~4 MB): tests and A/B runs switch it
+  const char* text = std::getenv("GFY_PACK_STREAM");
+  return text == nullptr || text[0] != '0';
+}
+
+// to[i] = from[i] - shift for `count` 32-bit values; returns the OR of (value | (limit - value))
+// over all of them: negative exactly when some value lies outside [0, limit]
+static int32_t copy_rebased(int32_t* to, const int32_t* from, int64_t count, int32_t shift,
+                            int32_t limit, bool stream) {
+  int32_t seen = 0;
+  int64_t i = 0;
+#if defined(__SSE2__)
+  if (stream) {
+    for (; i < count && (reinterpret_cast<uintptr_t>(to + i) & 15) != 0; ++i) {
+      const int32_t value = (int32_t)((uint32_t)from[i] - (uint32_t)shift);
+      to[i] = value;
+      seen |= value | (int32_t)((uint32_t)limit - (uint32_t)value);
+    }
+    const __m128i shifts = _mm_set1_epi32(shift), limits = _mm_set1_epi32(limit);
+    __m128i any = _mm_setzero_si128();
+    for (; i + 16 <= count; i += 16) {
+      __m128i v[4];
+      for (int k = 0; k < 4; ++k)
+        v[k] = _mm_sub_epi32(_mm_loadu_si128(reinterpret_cast<const __m128i*>(from + i + 4 * k)),
+                             shifts);
+      for (int k = 0; k < 4; ++k) {
+        any = _mm_or_si128(any, _mm_or_si128(v[k], _mm_sub_epi32(limits, v[k])));
+        _mm_stream_si128(reinterpret_cast<__m128i*>(to + i + 4 * k), v[k]);
+      }
+    }
+    alignas(16) int32_t lanes[4];
+    _mm_store_si128(reinterpret_cast<__m128i*>(lanes), any);
+    seen |= lanes[0] | lanes[1] | lanes[2] | lanes[3];
+  }
+#endif
+  for (; i < count; ++i) {
+    const int32_t value = (int32_t)((uint32_t)from[i] - (uint32_t)shift);
+    to[i] = value;
+    seen |= value | (int32_t)((uint32_t)limit - (uint32_t)value);
+  }
+  return seen;
+}
+
+static void copy_bytes(void* to_, const void* from_, size_t bytes, bool stream) {
+#if defined(__SSE2__)
+  if (stream && bytes >= 4096) {
+    char* to = static_cast<char*>(to_);
+    const char* from = static_cast<const char*>(from_);
+    const size_t head = (16 - (reinterpret_cast<uintptr_t>(to) & 15)) & 15;
+    memcpy(to, from, head);
+    size_t at = head;
+    for (; at + 64 <= bytes; at += 64) {
+      __m128i v[4];
+      for (int k = 0; k < 4; ++k)
+        v[k] = _mm_loadu_si128(reinterpret_cast<const __m128i*>(from + at + 16 * k));
+      for (int k = 0; k < 4; ++k)
+        _mm_stream_si128(reinterpret_cast<__m128i*>(to + at + 16 * k), v[k]);
+    }
+    memcpy(to + at, from + at, bytes - at);
+    return;
+  }
+#endif
+  memcpy(to_, from_, bytes);
 }
 
 }  // namespace gfy
@@ -65,31 +138,27 @@ int gfy_pack_microbatch(const float* node_features, int feature_dim, const int32
   }
   auto pad = [](int64_t bytes) { return (bytes + 255) / 256 * 256; };
   char* const out = static_cast<char*>(slot);
+  const bool stream = gfy::stream_stores();
   int64_t at = base;
   // node rows
   offsets[0] = at;
-  memcpy(out + at, node_features + n0 * feature_dim, (size_t)(n * feature_dim) * 4);
+  gfy::copy_bytes(out + at, node_features + n0 * feature_dim, (size_t)(n * feature_dim) * 4, stream);
   at += pad(n * feature_dim * 4);
   // edge_index, rebased; an index outside [0, n) in either row is the caller's error
   offsets[1] = at;
-  uint32_t largest = 0;
+  int32_t seen = 0;
   for (int row = 0; row < 2; ++row) {
     const int32_t* from = edge_index + (int64_t)row * edges_total + e0;
     int32_t* to = reinterpret_cast<int32_t*>(out + at) + (int64_t)row * e;
-    const int32_t shift = (int32_t)n0;
-    for (int64_t i = 0; i < e; ++i) {
-      const int32_t value = from[i] - shift;
-      to[i] = value;
-      largest = (uint32_t)value > largest ? (uint32_t)value : largest;
-    }
+    seen |= gfy::copy_rebased(to, from, e, (int32_t)n0, (int32_t)(n - 1), stream);
   }
-  if (e > 0 && (int64_t)largest >= n) {
+  if (e > 0 && seen < 0) {
     gfy::set_error("edge index outside shard node range");
     return GFY_ERR_INVALID;
   }
   at += pad(2 * e * 4);
   offsets[2] = at;
-  if (e > 0) memcpy(out + at, edge_types + e0, (size_t)e);
+  if (e > 0) gfy::copy_bytes(out + at, edge_types + e0, (size_t)e, stream);
   at += pad(e);
   // core rows: present only where a node of the range is not a core node (role != 0)
   bool any = false;
@@ -119,6 +188,9 @@ int gfy_pack_microbatch(const float* node_features, int feature_dim, const int32
     at += pad(bytes);
   }
   counts[0] = n, counts[1] = e, counts[2] = records ? stop - start : 0, counts[3] = kept;
+#if defined(__SSE2__)
+  if (stream) _mm_sfence();   // the streamed lines are in memory before the copy engine is told
+#endif
   return GFY_OK;
 }
 

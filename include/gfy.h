@@ -327,6 +327,25 @@ int gfy_pack_microbatch(const float* node_features, int feature_dim, const int32
                         const int64_t* edge_ptr, int64_t start, int64_t stop, int with_records,
                         void* slot, int64_t base, int64_t* offsets, int64_t* counts);
 
+/* ---- one packed group of micro-batches -> the device (libgfy.so only) ---------------------
+ * What follows gfy_pack_microbatch in the micro-batch loop of Ginfinity.encode_graphs
+ * (api.py:211-230: `batch.to(device)`).  A gfy_upload_ring owns one event per staging slot of
+ * its caller (`slots` of them, 1..64; made on the device that is current at creation).
+ * gfy_upload_async: `bytes` of page-locked staging memory (slot `slot`) go up by ONE
+ * asynchronous copy on `copy_stream`, and `consumer_stream` — the stream gfy_encode_coo_batch
+ * of that group is issued on — waits for it; nothing blocks the host.  gfy_upload_wait returns
+ * when the last upload from `slot` has left it, i.e. when a packer may write into it again (at
+ * once if there was none).  One call per group instead of a copy, two event records, a stream
+ * wait and a stream switch in the caller's interpreter (encode_shards_device: ~140 us of ~400
+ * per group of the launching thread, which is what bounds a rank fed from host arrays).  A ring
+ * is used by one thread at a time.                                                           */
+typedef struct gfy_upload_ring gfy_upload_ring;
+int gfy_upload_ring_create(int slots, gfy_upload_ring** ring_out);
+void gfy_upload_ring_destroy(gfy_upload_ring* ring);
+int gfy_upload_async(gfy_upload_ring* ring, int slot, void* device_dst, const void* pinned_src,
+                     size_t bytes, void* copy_stream, void* consumer_stream);
+int gfy_upload_wait(gfy_upload_ring* ring, int slot);
+
 /* ---- all-pairs distance over 128-d embeddings ----------------------------------
  * No reference symbol (the aligner lives in the external `ginfinity-sw`;
  * only parameters are exported: api.py:47-50, data/alignment.json:6) — defined

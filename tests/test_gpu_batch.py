@@ -274,6 +274,45 @@ def test_staged_groups_in_two_lanes_give_the_one_lane_bytes(gpu_encoder, rouskin
         want[sum(map(sum, counts[:1])):sum(map(sum, counts[:2]))].tobytes()
 
 
+def test_host_shards_in_two_lanes_give_the_one_lane_bytes(gpu_encoder, rouskin_shard, monkeypatch):
+    """``encode_shards_device`` (host arrays in, one device block out: what a rank of ``parallel``
+    runs) can keep two groups in flight as ``encode_staged`` does (``HOST_FEED_LANES``; the default
+    is one: the call is bound by the uploads), each behind its own upload.  Same
+    bytes as one group after the other and as the resident form, call after call into the same
+    block, with ragged groups, and with work of the caller's stream on both sides of the call."""
+    from ginfinity_amd import api
+    shards = [rouskin_shard, synthetic.roofline_shard(5), synthetic.arbitrary_shard(9),
+              synthetic.roofline_shard(6)]
+    monkeypatch.setattr(api, "HOST_FEED_LANES", 1)
+    want, want_counts = gpu_encoder.encode_shards_device(shards)
+    want = want.cpu().numpy()
+    staged, counts = gpu_encoder.stage_shards(shards)
+    assert len(staged) >= 16 and counts == want_counts
+    assert gpu_encoder.encode_staged(staged).cpu().numpy().tobytes() == want.tobytes()
+    monkeypatch.setattr(api, "HOST_FEED_LANES", 2)
+    block = torch.full(want.shape, float("nan"), dtype=torch.float16, device=gpu_encoder._engine.device)
+    for _ in range(3):
+        block.fill_(float("nan"))                       # on the caller's stream, in front of the call
+        got, got_counts = gpu_encoder.encode_shards_device(shards, out=block)
+        total = got.float().sum()                       # ... and behind it
+        assert got.cpu().numpy().tobytes() == want.tobytes() and got_counts == want_counts
+        assert bool(torch.isfinite(total))
+    for size in (3, 2):
+        monkeypatch.setattr(api, "MICROBATCH_GROUP", size)
+        assert gpu_encoder.encode_shards_device(shards)[0].cpu().numpy().tobytes() == want.tobytes()
+    # an error of a packer (an edge that leaves its records) leaves the lanes usable
+    broken = synthetic.roofline_shard(1, records=3, length=100)
+    edges = broken.edge_index.copy()
+    edges[0, 5] = 250
+    object.__setattr__(broken, "edge_index", edges)
+    monkeypatch.setattr(api, "MICROBATCH_GROUP", 2)     # 100-node micro-batches, pairs: 2 good groups, then the bad one
+    with pytest.raises(Exception, match="edge index outside"):
+        gpu_encoder.encode_shards_device([synthetic.roofline_shard(2, records=4, length=100), broken],
+                                         max_batch_nodes=150)
+    monkeypatch.setattr(api, "MICROBATCH_GROUP", 4)
+    assert gpu_encoder.encode_shards_device(shards)[0].cpu().numpy().tobytes() == want.tobytes()
+
+
 def _device_with_records(engine, shard):
     """As ``_device``, with the shard's record boundaries riding on the edge_index tensor (what
     ``Ginfinity.stage_shards`` uploads): the batch call then takes the record-range set-up."""

@@ -469,15 +469,19 @@ def test_record_boundaries_ride_on_the_edge_index_tensor():
     assert names[-3:] == ["node_ptr", "edge_ptr", "n_records"] and native.ABI_VERSION == 4
 
 
-def test_native_packer_writes_the_bytes_of_the_numpy_packer():
+@pytest.mark.parametrize("stream", ["1", "0"])
+def test_native_packer_writes_the_bytes_of_the_numpy_packer(stream, monkeypatch):
     """``gfy_pack_microbatch`` (csrc/gfy_base.cpp: one call without the interpreter lock) against
     ``_pack_microbatch_at`` + ``_Uploader.pack_at`` in numpy: the same offsets, counts and staging
     bytes — whole shards and record ranges in the middle (edge_index rebased), context rows
     (``out_rows``), a record too long for record boundaries, one-record and one-node ranges — and
-    the reference's error for an edge that leaves the records' node range (graph.py:318-321)."""
+    the reference's error for an edge that leaves the records' node range on either side
+    (graph.py:318-321).  Both forms of its copies: streaming stores (the default) and memcpy
+    (``GFY_PACK_STREAM=0``)."""
     import torch
     from ginfinity_amd import api, synthetic
     from ginfinity_amd.spec import GraphValidationError
+    monkeypatch.setenv("GFY_PACK_STREAM", stream)
 
     class Slots(api._Uploader):
         def __init__(self):
@@ -509,11 +513,14 @@ def test_native_packer_writes_the_bytes_of_the_numpy_packer():
     broken = synthetic.roofline_shard(1, records=3, length=100)
     edges = broken.edge_index.copy()
     edges[0, 5] = 250                                   # record 0's edge points into record 2
+    edges[1, int(broken.edge_ptr[1]) + 7] = 3           # record 1's edge points into record 0
     object.__setattr__(broken, "edge_index", edges)
     for native_packer in (True, False):
         api.NATIVE_PACKER = native_packer
         try:
             with pytest.raises(GraphValidationError, match="edge index outside"):
                 api.Ginfinity._pack_microbatch_at(slots, 0, 0, broken, 0, 1)
+            with pytest.raises(GraphValidationError, match="edge index outside"):
+                api.Ginfinity._pack_microbatch_at(slots, 0, 0, broken, 1, 2)   # ... and record 1's below it
         finally:
             api.NATIVE_PACKER = True
