@@ -345,7 +345,9 @@ def cross_shard(args, rank: int, local_rank: int, world: int, distributed: bool,
     # compute (Ginfinity.encode_shards_device), what parallel.encode_owned_shards runs
     streamed_s = None
     if on_gpu and owned:
-        encoder.encode_shards_device([shards[s] for s in owned], out=block)      # warm
+        for _ in range(2):      # warm: the second call reaches the staging ring's other slots
+            encoder.encode_shards_device([shards[s] for s in owned], out=block)   # (page-locked
+                                                                                  # allocations)
         fence()
         t0 = time.perf_counter()
         encoder.encode_shards_device([shards[s] for s in owned], out=block)

@@ -59,6 +59,15 @@ def test_argument_errors_without_a_gpu(checkpoint):
     assert lib.gfy_encode(None, None, None, None, None, 1, 0, None, None, 0, 1, None, 0,
                           None) == native.GFY_ERR_INVALID
     assert lib.gfy_csr_workspace_bytes(60_000, 300_000) > 2 * 4 * 300_000
+    # the upload ring refuses what it can without a device
+    ring = ctypes.c_void_p()
+    for slots in (0, 65):
+        assert lib.gfy_upload_ring_create(slots, ctypes.byref(ring)) == native.GFY_ERR_INVALID
+        assert b"1..64" in lib.gfy_last_error() and not ring.value
+    assert lib.gfy_upload_ring_create(8, None) == native.GFY_ERR_INVALID
+    assert lib.gfy_upload_async(None, 0, None, None, 0, None, None) == native.GFY_ERR_INVALID
+    assert lib.gfy_upload_wait(None, 0) == native.GFY_ERR_INVALID
+    lib.gfy_upload_ring_destroy(None)
 
 
 def test_layer_kernel_keeps_its_register_and_scratch_budget():
