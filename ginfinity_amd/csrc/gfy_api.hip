@@ -776,7 +776,9 @@ static int batch_table(const gfy_shard* shards, int count, const char* who, Shar
     RecordTable r{};
     bool all = true;
     int ranges = 0;
-    r.range_rows = t.total_rows() <= kRecSmallBatchRows ? kRecRowsSmall : kRecRowsLarge;
+    r.range_rows = t.total_rows() <= kRecLoneBatchRows    ? kRecRowsLone
+                   : t.total_rows() <= kRecSmallBatchRows ? kRecRowsSmall
+                                                          : kRecRowsLarge;
     for (int s = 0; s < count; ++s) {
       const gfy_shard& one = shards[s];
       const bool given = one.node_ptr && one.edge_ptr && one.n_records > 0;

@@ -229,7 +229,14 @@ struct ShardTable {
 // launch — 512 / 768 rows cost it 4 / 10 us), kRecRowsLarge above (four shards: the scan of a
 // workgroup covers its records once for three times the rows, and fewer workgroups stand in the
 // way of the input Linear's: 41.7 -> 37.2 us; 512 rows 37.9, 1,024 rows 41.5).
-constexpr int kRecRowsSmall = 256, kRecRowsLarge = 768;
+// A batch of up to kRecLoneBatchRows rows (a lone 60,000-node micro-batch) takes 512 rows per
+// workgroup of 512 THREADS: the launch is one workgroup's latency chain there, and eight waves
+// halve its scan and its turns (set-up 19.2-20.0 -> 18.0-18.7 us, a call 97.4 -> 95.9 us; 8,000
+// nodes 81.6 -> 80.4; 120,000 nodes +1 us, 180,000 +3.3 us, 240,000 rows with 512 / 384 threads
+// +6-7 us beside the Linear's workgroups, which get the same size: profiles/README.md).
+constexpr int kRecRowsLone = 512, kRecRowsSmall = 256, kRecRowsLarge = 768;
+constexpr int kRecThreadsLone = 512, kRecThreadsSmall = 256, kRecThreadsLarge = 256;
+constexpr int64_t kRecLoneBatchRows = 90000;
 constexpr int64_t kRecSmallBatchRows = 200000;   // 180,000 rows: 220.3 (256) against 222.0 us (768) per call; 210,000: 253 / 252; 240,000: 278 / 276
 struct RecordTable {
   const int64_t* node_ptr[kMaxBatchShards];   // [records + 1], shard-local, ascending

@@ -523,14 +523,16 @@ static int encode_f16_on(const gfy_encoder* enc, const ShardTable& shards, const
 #else
       const int ranges = coo->records->range_base[shards.shards], linear = linear_blocks;
 #endif
-      if (coo->records->range_rows == kRecRowsLarge)
-        k_encode_setup_rec<kRecRowsLarge><<<ranges + linear, 256, 0, s>>>(
-            shards, *coo->records, enc->f16.w_in, enc->f16.b_in, ha, coo->row_ptr, coo->col,
-            coo->typ, coo->scratch.perm, plans, ranges, enc->edge_dim);
-      else
-        k_encode_setup_rec<kRecRowsSmall><<<ranges + linear, 256, 0, s>>>(
-            shards, *coo->records, enc->f16.w_in, enc->f16.b_in, ha, coo->row_ptr, coo->col,
-            coo->typ, coo->scratch.perm, plans, ranges, enc->edge_dim);
+      // the Linear's workgroups have the range workgroups' size: the same number of threads
+#define GFY_LAUNCH_SETUP_REC(ROWS, THREADS)                                                   \
+  k_encode_setup_rec<ROWS, THREADS>                                                           \
+      <<<ranges + (linear * 256 + THREADS - 1) / THREADS, THREADS, 0, s>>>(                   \
+          shards, *coo->records, enc->f16.w_in, enc->f16.b_in, ha, coo->row_ptr, coo->col,    \
+          coo->typ, coo->scratch.perm, plans, ranges, enc->edge_dim)
+      if (coo->records->range_rows == kRecRowsLarge) GFY_LAUNCH_SETUP_REC(kRecRowsLarge, kRecThreadsLarge);
+      else if (coo->records->range_rows == kRecRowsSmall) GFY_LAUNCH_SETUP_REC(kRecRowsSmall, kRecThreadsSmall);
+      else GFY_LAUNCH_SETUP_REC(kRecRowsLone, kRecThreadsLone);
+#undef GFY_LAUNCH_SETUP_REC
     }
     else if (coo && coo->scan_free)   // + last CSR stage (row offsets included) + tile plans
       k_encode_setup_coo<false><<<layer_tiles + linear_blocks, 256, 0, s>>>(

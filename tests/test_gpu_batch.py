@@ -363,11 +363,12 @@ def test_record_boundaries_change_nothing_but_the_launches(gpu_encoder, mixed_sh
 
 
 def test_record_ranges_of_both_sizes_give_the_counting_path_bytes(gpu_encoder):
-    """The range workgroups own 256 rows in a batch of up to 200,000 rows and 768 above
-    (gfy_common.h: kRecRowsSmall / kRecRowsLarge): the same shards alone (small ranges) and
-    in one batch of 203,500 rows (large ranges; direct-path tiles and hub rows inside them, a
-    shard whose last range is ragged, shard bases that are no multiple of 768) give the bytes of
-    the counting path."""
+    """The range workgroups own 512 rows (and have 512 threads) in a batch of up to 90,000 rows,
+    256 rows up to 200,000 and 768 above (gfy_common.h: kRecRowsLone / kRecRowsSmall /
+    kRecRowsLarge): the same shards alone and in a batch of 83,500 rows (the 512-thread
+    workgroups), in one of 140,000 rows (small ranges) and in one of 203,500 rows (large ranges;
+    direct-path tiles and hub rows inside them, a shard whose last range is ragged, shard bases
+    that are no multiple of the range) give the bytes of the counting path."""
     engine = gpu_encoder._engine
     shards = [synthetic.roofline_shard(0), synthetic.roofline_shard(1),
               synthetic.arbitrary_shard(3, nodes=20_000, edges=90_000, records=5, hub_degree=60),
@@ -375,7 +376,8 @@ def test_record_ranges_of_both_sizes_give_the_counting_path_bytes(gpu_encoder):
               synthetic.roofline_shard(4)]
     assert sum(s.node_count for s in shards) > 200_000
     alone = [engine.encode_coo_batch([_device(engine, s)])[0].cpu().numpy() for s in shards]
-    for group in ([[s] for s in shards] + [shards, shards[2:], shards[::-1]]):
+    assert sum(s.node_count for s in shards[2:]) <= 90_000 < sum(s.node_count for s in shards[:3])
+    for group in ([[s] for s in shards] + [shards, shards[2:], shards[:3], shards[::-1]]):
         ranged = [o.cpu().numpy() for o in
                   engine.encode_coo_batch([_device_with_records(engine, s) for s in group])]
         for got, shard in zip(ranged, group):
